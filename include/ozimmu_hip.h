@@ -1,0 +1,159 @@
+/*
+ * ozimmu_hip.h — C ABI of libozimmu_hip.so: Ozaki-scheme (INT8 MFMA) DGEMM for MI355X (gfx950).
+ *
+ * Two boundaries, both drop-ins for enp1s0/ozIMMU's (citations relative to /root/reference):
+ *
+ * 1. LD_PRELOAD interposer (replaces src/cublas.cu:103-513, the `extern "C"` cuBLAS symbols).
+ *    The library DEFINES the following rocBLAS / hipBLAS entry points with their vendor prototypes
+ *    (<rocblas/rocblas.h>, <hipblas/hipblas.h>); anything it does not take over is forwarded to the
+ *    next definition found with dlsym(RTLD_NEXT, ...) exactly like src/utils.hpp:117-141:
+ *
+ *      rocblas_create_handle, rocblas_destroy_handle      <- cublasCreate_v2 / cublasDestroy_v2 (src/cublas.cu:104-131)
+ *      rocblas_dgemm, rocblas_dgemm_64                    <- cublasDgemm_v2 (src/cublas.cu:280-295)
+ *      rocblas_gemm_ex (all-f64_r case)                   <- cublasGemmEx   (src/cublas.cu:133-278)
+ *      rocblas_dgemm_strided_batched                      <- cublasDgemmStridedBatched (src/cublas.cu:474-492)
+ *      hipblasDgemm, hipblasGemmEx (HIP_R_64F case)       <- same, for applications that bind hipBLAS
+ *                                                            directly (hipBLAS itself calls rocblas_dgemm)
+ *
+ *    Environment (src/cublas.cu:18-48, :62-83; src/handle.cu:25-30; src/utils.hpp:88-115; README.md:54-77):
+ *      OZIMMU_COMPUTE_MODE = dgemm | sgemm | fp64_int8_3..fp64_int8_18 | fp64_int8_auto  (read per call;
+ *                            unset/unknown -> dgemm = pass through; sgemm -> pass through, documented)
+ *      OZIMMU_INTERCEPT_THRESHOLD_M / _N / _K (default 1024), OZIMMU_AUTO_AVG_MANTISSA_LOSS_THRESHOLD,
+ *      OZIMMU_INFO, OZIMMU_ERROR, OZIMMU_MALLOC_ASYNC, OZIMMU_ENABLE_CULIP_PROFILING.
+ *
+ * 2. Direct library API (replaces include/ozimmu/ozimmu.hpp:47-100, the `mtk::ozimmu::` C++ API that the
+ *    reference's own test harness calls, test/main_test.cu:242).  Same names, argument order and return
+ *    conventions, flattened to C: no exceptions cross this boundary.
+ *
+ * All pointers to matrices are DEVICE pointers (column-major); alpha/beta are HOST pointers
+ * (src/gemm.cu:405 dereferences them on the host).  Work is enqueued on the handle's stream; nothing here
+ * synchronises the device.
+ */
+#ifndef OZIMMU_HIP_H
+#define OZIMMU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ozimmu_hip_handle *ozimmu_hip_handle_t; /* include/ozimmu/ozimmu.hpp:9-11 */
+
+typedef enum { OZIMMU_OP_N = 0, OZIMMU_OP_T = 1 } ozimmu_operation_t; /* ozimmu.hpp:12 */
+
+/* include/ozimmu/ozimmu.hpp:14-37 — same order, so the integer values match the reference enum */
+typedef enum {
+  OZIMMU_SGEMM = 0,
+  OZIMMU_DGEMM = 1,
+  OZIMMU_FP64_INT8_3 = 2,
+  OZIMMU_FP64_INT8_4,
+  OZIMMU_FP64_INT8_5,
+  OZIMMU_FP64_INT8_6,
+  OZIMMU_FP64_INT8_7,
+  OZIMMU_FP64_INT8_8,
+  OZIMMU_FP64_INT8_9,
+  OZIMMU_FP64_INT8_10,
+  OZIMMU_FP64_INT8_11,
+  OZIMMU_FP64_INT8_12,
+  OZIMMU_FP64_INT8_13,
+  OZIMMU_FP64_INT8_14,
+  OZIMMU_FP64_INT8_15,
+  OZIMMU_FP64_INT8_16,
+  OZIMMU_FP64_INT8_17,
+  OZIMMU_FP64_INT8_18,
+  OZIMMU_FP64_INT8_AUTO
+} ozimmu_compute_mode_t;
+
+typedef enum { OZIMMU_MALLOC_SYNC = 0, OZIMMU_MALLOC_ASYNC = 1 } ozimmu_malloc_mode_t; /* ozimmu.hpp:41 */
+typedef enum { OZIMMU_REAL = 0, OZIMMU_COMPLX = 1 } ozimmu_element_kind_t;            /* ozimmu.hpp:43-46 */
+typedef enum { OZIMMU_MATRIX_A = 0, OZIMMU_MATRIX_B = 1 } ozimmu_matrix_t;            /* src/config.hpp:9 */
+
+/* ozimmu.hpp:48-49 (src/handle.cu:6-52).  Return 0 on success. */
+int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm);
+int ozimmu_hip_destroy(ozimmu_hip_handle_t handle);
+
+/* ozimmu.hpp:50-51 set_cuda_stream (src/handle.cu:54-61). `hip_stream` is a hipStream_t. */
+void ozimmu_hip_set_stream(ozimmu_hip_handle_t handle, void *hip_stream);
+
+/* ozimmu.hpp:53-57 (src/handle.cu:246-265): stage breakdown split_A/split_B/int8tc/accumulate_in_f64/copy_result */
+void ozimmu_hip_enable_profiling(ozimmu_hip_handle_t handle);
+void ozimmu_hip_disable_profiling(ozimmu_hip_handle_t handle);
+void ozimmu_hip_print_profiler_result(ozimmu_hip_handle_t handle, const char *tag, int csv);
+void ozimmu_hip_clear_profiler_result(ozimmu_hip_handle_t handle);
+
+/* ozimmu.hpp:59-61 (the reference never defines the getter in its namespace: src/handle.cu:272-274) */
+void ozimmu_hip_set_auto_mantissa_loss_threashold(ozimmu_hip_handle_t handle, double threshold);
+double ozimmu_hip_get_auto_mantissa_loss_threashold(ozimmu_hip_handle_t handle);
+
+/* ozimmu.hpp:69-74.  Returns the new size if the workspace grew, else 0 (src/handle.cu:63-93). */
+size_t ozimmu_hip_reallocate_working_memory(ozimmu_hip_handle_t handle, size_t size_in_byte);
+/* size one GEMM needs (the gemm_list_t overload, src/handle.cu:95-144, one entry at a time) */
+size_t ozimmu_hip_working_memory_size(ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m, size_t n,
+                                      size_t k, ozimmu_element_kind_t element_kind,
+                                      ozimmu_compute_mode_t compute_mode);
+
+/* ozimmu.hpp:75-82 (src/gemm.cu:524-653).  0 ok; 1 invalid shape / alignment (src/gemm.cu:554-556);
+ * 2 unsupported (complex: next row F1); 3 HIP failure (the reference would throw). */
+int ozimmu_hip_gemm(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                    size_t n, size_t k, const void *alpha, const void *a_ptr, size_t lda, const void *b_ptr,
+                    size_t ldb, const void *beta, void *c_ptr, size_t ldc,
+                    ozimmu_compute_mode_t compute_mode, ozimmu_element_kind_t element_kind);
+
+/* ozimmu.hpp:84-94 (src/split.cu:454-518).  Blocks on one 128-byte D2H copy like the reference (:404-408).
+ * Returns a fp64_int8_N mode or OZIMMU_DGEMM when no N in 3..18 meets the threshold. */
+ozimmu_compute_mode_t ozimmu_hip_auto_mode_select(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A,
+                                                  ozimmu_operation_t op_B, size_t m, size_t n, size_t k,
+                                                  const void *a_ptr, size_t lda, const void *b_ptr,
+                                                  size_t ldb, ozimmu_element_kind_t element_kind,
+                                                  double mantissa_loss_threshold);
+
+/* ozimmu.hpp:96 (src/handle.cu:146-192): "fp64_int8_9", ...; NULL for an invalid enum value */
+const char *ozimmu_hip_get_compute_mode_name_str(ozimmu_compute_mode_t mode);
+/* inverse, as used by src/cublas.cu:18-48: unknown / NULL -> OZIMMU_DGEMM */
+ozimmu_compute_mode_t ozimmu_hip_compute_mode_from_str(const char *name);
+/* ozimmu.hpp:100 (src/split.cu:520-536) */
+uint32_t ozimmu_hip_get_bits_per_int8(uint32_t k);
+/* number of slices of a mode: 3..18, 0 otherwise (src/config.cu:28-80) */
+int ozimmu_hip_get_num_split(ozimmu_compute_mode_t mode);
+
+/* ---- stage-level entry points (the reference's internal stage functions, exposed for parity tests) ---- */
+
+/* src/split.hpp:12-19 split_int8<double>: slices of A (matrix_A: m x k view of op(A)) or of B (matrix_B:
+ * the k x n op(B), rows = n), written in the REFERENCE layout out[s][row][ldo] (ldo >= padded k) plus
+ * max_exp[row].  All device pointers.  Internally runs the production kernels (tiled planes) and then a
+ * re-layout kernel. */
+int ozimmu_hip_split_int8(ozimmu_hip_handle_t handle, int8_t *out_ptr, uint32_t ldo, double *max_exp_ptr,
+                          size_t m, size_t n, const double *in_ptr, size_t ld, ozimmu_operation_t op,
+                          ozimmu_matrix_t matrix, unsigned num_split, unsigned bits_per_int8);
+
+/* INT32 sums per diagonal t = i+j (t = 2..S+1) of the slice products, out[t-2][n][m] (device, int32):
+ * what the fused kernel holds in its accumulators before the FP64 recombination; equals the sum over the
+ * reference's per-pair cublasGemmEx results (src/gemm.cu:315-329) with i+j = t. */
+int ozimmu_hip_diagonal_sums(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A, ozimmu_operation_t op_B,
+                             size_t m, size_t n, size_t k, const double *a_ptr, size_t lda,
+                             const double *b_ptr, size_t ldb, unsigned num_split, int32_t *out);
+
+/* src/split.hpp:21-27 get_mantissa_loss_total for both operands: counters[S-3], S = 3..18 (host array of 16) */
+int ozimmu_hip_mantissa_loss(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A, ozimmu_operation_t op_B,
+                             size_t m, size_t n, size_t k, const double *a_ptr, size_t lda,
+                             const double *b_ptr, size_t ldb, uint64_t counters[16]);
+
+/* native FP64 GEMM through the real rocBLAS (the `dgemm` mode of src/gemm.cu:639-645); also bench.py's
+ * rocBLAS comparison point.  0 ok, nonzero rocblas_status otherwise. */
+int ozimmu_hip_native_dgemm(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A, ozimmu_operation_t op_B,
+                            size_t m, size_t n, size_t k, const double *alpha, const double *a_ptr,
+                            size_t lda, const double *b_ptr, size_t ldb, const double *beta, double *c_ptr,
+                            size_t ldc);
+
+/* timing of the last ozimmu_hip_gemm per stage in milliseconds (HIP events on the handle's stream; only
+ * when profiling is enabled).  stages: 0 split_A, 1 split_B, 2 int8tc (fused with accumulate/copy) */
+int ozimmu_hip_last_stage_ms(ozimmu_hip_handle_t handle, float ms[3]);
+
+const char *ozimmu_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,248 @@
+"""ozimmu_amd — Python host-side mirror of libozimmu_hip.so (Ozaki-scheme INT8-MFMA DGEMM for MI355X).
+
+The product is the C-ABI shared library (include/ozimmu_hip.h): an LD_PRELOAD drop-in for
+rocBLAS/hipBLAS DGEMM plus the direct API of the reference's include/ozimmu/ozimmu.hpp:47-100.
+This module only binds that ABI with ctypes, using the reference's names and argument order
+(`create`, `destroy`, `set_cuda_stream`, `gemm`, `auto_mode_select`, ...), so tests read like the
+reference's own harness (test/main_test.cu:242).  PyTorch is used for device memory and streams only.
+
+There is NO CPU fallback: if the HIP library is missing the import of any compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libozimmu_hip.so")
+
+# include/ozimmu/ozimmu.hpp:12
+op_n, op_t = 0, 1
+# include/ozimmu/ozimmu.hpp:14-37
+(sgemm, dgemm, fp64_int8_3, fp64_int8_4, fp64_int8_5, fp64_int8_6, fp64_int8_7, fp64_int8_8,
+ fp64_int8_9, fp64_int8_10, fp64_int8_11, fp64_int8_12, fp64_int8_13, fp64_int8_14, fp64_int8_15,
+ fp64_int8_16, fp64_int8_17, fp64_int8_18, fp64_int8_auto) = range(19)
+malloc_sync, malloc_async = 0, 1
+real, complx = 0, 1
+matrix_A, matrix_B = 0, 1
+
+_lib = None
+
+
+class OzimmuLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libozimmu_hip.so (built by `python -m ozimmu_amd.build`).  Import torch first in a process
+    that uses both, so a single HIP runtime (libamdhip64.so.7) is shared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OzimmuLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m ozimmu_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i, d, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_uint32
+    L.ozimmu_hip_version.restype = C.c_char_p
+    L.ozimmu_hip_create.restype = i
+    L.ozimmu_hip_create.argtypes = [C.POINTER(vp), i]
+    L.ozimmu_hip_destroy.restype = i
+    L.ozimmu_hip_destroy.argtypes = [vp]
+    L.ozimmu_hip_set_stream.restype = None
+    L.ozimmu_hip_set_stream.argtypes = [vp, vp]
+    for f in ("enable_profiling", "disable_profiling", "clear_profiler_result"):
+        getattr(L, "ozimmu_hip_" + f).restype = None
+        getattr(L, "ozimmu_hip_" + f).argtypes = [vp]
+    L.ozimmu_hip_print_profiler_result.restype = None
+    L.ozimmu_hip_print_profiler_result.argtypes = [vp, C.c_char_p, i]
+    L.ozimmu_hip_set_auto_mantissa_loss_threashold.restype = None
+    L.ozimmu_hip_set_auto_mantissa_loss_threashold.argtypes = [vp, d]
+    L.ozimmu_hip_get_auto_mantissa_loss_threashold.restype = d
+    L.ozimmu_hip_get_auto_mantissa_loss_threashold.argtypes = [vp]
+    L.ozimmu_hip_reallocate_working_memory.restype = sz
+    L.ozimmu_hip_reallocate_working_memory.argtypes = [vp, sz]
+    L.ozimmu_hip_working_memory_size.restype = sz
+    L.ozimmu_hip_working_memory_size.argtypes = [i, i, sz, sz, sz, i, i]
+    L.ozimmu_hip_gemm.restype = i
+    L.ozimmu_hip_gemm.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz, i, i]
+    L.ozimmu_hip_auto_mode_select.restype = i
+    L.ozimmu_hip_auto_mode_select.argtypes = [vp, i, i, sz, sz, sz, vp, sz, vp, sz, i, d]
+    L.ozimmu_hip_get_compute_mode_name_str.restype = C.c_char_p
+    L.ozimmu_hip_get_compute_mode_name_str.argtypes = [i]
+    L.ozimmu_hip_compute_mode_from_str.restype = i
+    L.ozimmu_hip_compute_mode_from_str.argtypes = [C.c_char_p]
+    L.ozimmu_hip_get_bits_per_int8.restype = u32
+    L.ozimmu_hip_get_bits_per_int8.argtypes = [u32]
+    L.ozimmu_hip_get_num_split.restype = i
+    L.ozimmu_hip_get_num_split.argtypes = [i]
+    L.ozimmu_hip_split_int8.restype = i
+    L.ozimmu_hip_split_int8.argtypes = [vp, vp, u32, vp, sz, sz, vp, sz, i, i, C.c_uint, C.c_uint]
+    L.ozimmu_hip_diagonal_sums.restype = i
+    L.ozimmu_hip_diagonal_sums.argtypes = [vp, i, i, sz, sz, sz, vp, sz, vp, sz, C.c_uint, vp]
+    L.ozimmu_hip_mantissa_loss.restype = i
+    L.ozimmu_hip_mantissa_loss.argtypes = [vp, i, i, sz, sz, sz, vp, sz, vp, sz, C.POINTER(C.c_uint64)]
+    L.ozimmu_hip_native_dgemm.restype = i
+    L.ozimmu_hip_native_dgemm.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz]
+    L.ozimmu_hip_last_stage_ms.restype = i
+    L.ozimmu_hip_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def _ptr(x):
+    """device pointer of a torch tensor, or an int passed through"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+def _op(op):
+    if isinstance(op, str):
+        return op_n if op.upper() == "N" else op_t
+    return int(op)
+
+
+def _mode(mode):
+    if isinstance(mode, str):
+        m = lib().ozimmu_hip_compute_mode_from_str(mode.encode())
+        if mode != "dgemm" and m == dgemm:
+            raise ValueError(f"unknown compute mode {mode!r}")
+        return m
+    return int(mode)
+
+
+class handle_t:
+    """mtk::ozimmu::handle_t"""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
+def create(malloc_mode=malloc_sync):
+    p = C.c_void_p()
+    st = lib().ozimmu_hip_create(C.byref(p), malloc_mode)
+    if st != 0 or not p.value:
+        raise RuntimeError(f"ozimmu_hip_create failed (status {st}); is a GPU visible?")
+    return handle_t(p)
+
+
+def destroy(handle):
+    if handle is not None and handle.ptr:
+        lib().ozimmu_hip_destroy(handle.ptr)
+        handle.ptr = None
+    return 0
+
+
+def set_cuda_stream(handle, stream):
+    """`stream`: a torch.cuda.Stream, or a raw hipStream_t as int (0 = default stream)."""
+    raw = getattr(stream, "cuda_stream", stream)
+    lib().ozimmu_hip_set_stream(handle.ptr, C.c_void_p(int(raw) if raw else 0))
+
+
+set_stream = set_cuda_stream
+
+
+def enable_profiling(handle):
+    lib().ozimmu_hip_enable_profiling(handle.ptr)
+
+
+def disable_profiling(handle):
+    lib().ozimmu_hip_disable_profiling(handle.ptr)
+
+
+def print_profiler_result(handle, tag, csv=False):
+    lib().ozimmu_hip_print_profiler_result(handle.ptr, tag.encode(), int(csv))
+
+
+def clear_profiler_result(handle):
+    lib().ozimmu_hip_clear_profiler_result(handle.ptr)
+
+
+def last_stage_ms(handle):
+    ms = (C.c_float * 3)()
+    lib().ozimmu_hip_last_stage_ms(handle.ptr, ms)
+    return {"split_A": ms[0], "split_B": ms[1], "int8tc": ms[2]}
+
+
+def set_auto_mantissa_loss_threashold(handle, threshold):
+    lib().ozimmu_hip_set_auto_mantissa_loss_threashold(handle.ptr, float(threshold))
+
+
+def get_auto_mantissa_loss_threashold(handle):
+    return float(lib().ozimmu_hip_get_auto_mantissa_loss_threashold(handle.ptr))
+
+
+def reallocate_working_memory(handle, size_or_gemm_list):
+    """size in bytes, or the reference's gemm_list_t: [(op_A, op_B, m, n, k, element_kind, mode), ...]"""
+    if isinstance(size_or_gemm_list, int):
+        size = size_or_gemm_list
+    else:
+        size = 0
+        for (oa, ob, m, n, k, kind, mode) in size_or_gemm_list:
+            size = max(size, lib().ozimmu_hip_working_memory_size(_op(oa), _op(ob), m, n, k, kind, _mode(mode)))
+    return int(lib().ozimmu_hip_reallocate_working_memory(handle.ptr, size))
+
+
+def gemm(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc, compute_mode,
+         element_kind=real):
+    """mtk::ozimmu::gemm (include/ozimmu/ozimmu.hpp:75-82).  alpha/beta: Python floats (host scalars);
+    a/b/c: column-major device buffers (torch tensors or raw pointers).  Returns the int status."""
+    al, be = C.c_double(alpha), C.c_double(beta)
+    return int(lib().ozimmu_hip_gemm(handle.ptr, _op(op_A), _op(op_B), m, n, k, C.addressof(al), _ptr(a_ptr), lda,
+                                     _ptr(b_ptr), ldb, C.addressof(be), _ptr(c_ptr), ldc, _mode(compute_mode),
+                                     element_kind))
+
+
+def native_dgemm(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc):
+    al, be = C.c_double(alpha), C.c_double(beta)
+    return int(lib().ozimmu_hip_native_dgemm(handle.ptr, _op(op_A), _op(op_B), m, n, k, C.addressof(al),
+                                             _ptr(a_ptr), lda, _ptr(b_ptr), ldb, C.addressof(be), _ptr(c_ptr), ldc))
+
+
+def auto_mode_select(handle, op_A, op_B, m, n, k, a_ptr, lda, b_ptr, ldb, element_kind, mantissa_loss_threshold):
+    return int(lib().ozimmu_hip_auto_mode_select(handle.ptr, _op(op_A), _op(op_B), m, n, k, _ptr(a_ptr), lda,
+                                                 _ptr(b_ptr), ldb, element_kind, float(mantissa_loss_threshold)))
+
+
+def mantissa_loss(handle, op_A, op_B, m, n, k, a_ptr, lda, b_ptr, ldb):
+    cnt = (C.c_uint64 * 16)()
+    st = lib().ozimmu_hip_mantissa_loss(handle.ptr, _op(op_A), _op(op_B), m, n, k, _ptr(a_ptr), lda, _ptr(b_ptr),
+                                        ldb, cnt)
+    if st:
+        raise RuntimeError(f"ozimmu_hip_mantissa_loss failed ({st})")
+    return list(cnt)
+
+
+def split_int8(handle, out_ptr, ldo, max_exp_ptr, m, n, in_ptr, ld, op, matrix, num_split, bits_per_int8):
+    """mtk::ozimmu::split_int8<double> (src/split.hpp:12-19); reference output layout."""
+    return int(lib().ozimmu_hip_split_int8(handle.ptr, _ptr(out_ptr), ldo, _ptr(max_exp_ptr), m, n, _ptr(in_ptr), ld,
+                                           _op(op), matrix, num_split, bits_per_int8))
+
+
+def diagonal_sums(handle, op_A, op_B, m, n, k, a_ptr, lda, b_ptr, ldb, num_split, out_ptr):
+    return int(lib().ozimmu_hip_diagonal_sums(handle.ptr, _op(op_A), _op(op_B), m, n, k, _ptr(a_ptr), lda,
+                                              _ptr(b_ptr), ldb, num_split, _ptr(out_ptr)))
+
+
+def get_compute_mode_name_str(mode):
+    s = lib().ozimmu_hip_get_compute_mode_name_str(int(mode))
+    if s is None:
+        raise ValueError("Not implemented (invalid compute mode)")
+    return s.decode()
+
+
+def get_bits_per_int8(k):
+    return int(lib().ozimmu_hip_get_bits_per_int8(int(k)))
+
+
+def get_num_split(mode):
+    return int(lib().ozimmu_hip_get_num_split(_mode(mode)))
+
+
+def version():
+    return lib().ozimmu_hip_version().decode()
+
+
+PRELOAD_ENV = {"LD_PRELOAD": LIB_PATH}

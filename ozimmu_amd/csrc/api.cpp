@@ -1,0 +1,513 @@
+// api.cpp — direct library API (C ABI of include/ozimmu_hip.h) and the Ozaki DGEMM host pipeline.
+//
+// Mirrors the reference's L3/L2 host layers (citations relative to /root/reference):
+//   handle lifecycle + grow-only workspace   src/handle.cu:6-144
+//   mtk::ozimmu::gemm dispatcher             src/gemm.cu:524-653
+//   gemm_int8<double> orchestration          src/gemm.cu:344-410
+//   auto_mode_select                         src/split.cu:454-518
+// The device stages are in split.hip and slice_gemm.hip.  No exception crosses the C ABI and nothing
+// here synchronises the device except where the reference's semantics need a host value (auto mode).
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rocblas/rocblas.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "handle.h"
+#include "kernels.h"
+#include "layout.h"
+
+using namespace ozhip;
+
+// ---- small helpers -----------------------------------------------------------------------------------
+
+namespace ozhip {
+
+void *vendor_symbol(const char *name) {
+  void *f = dlsym(RTLD_NEXT, name);
+  if (f) return f;
+  const bool hipblas = std::strncmp(name, "hipblas", 7) == 0;
+  const char *lib = hipblas ? "libhipblas.so.3" : "librocblas.so.5";
+  void *h = dlopen(lib, RTLD_NOW | RTLD_NOLOAD); // the copy the process already uses (e.g. PyTorch's)
+  if (!h) h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    log_error(std::string("Failed to load ") + lib + ".");
+    return nullptr;
+  }
+  f = dlsym(h, name);
+  if (!f)
+    log_error(std::string("Failed to load a function ") + name +
+              " during selecting hijacking function. Default rule will be used.");
+  return f;
+}
+
+static const char *const kModeNames[] = {
+    "sgemm",        "dgemm",        "fp64_int8_3",  "fp64_int8_4",  "fp64_int8_5",
+    "fp64_int8_6",  "fp64_int8_7",  "fp64_int8_8",  "fp64_int8_9",  "fp64_int8_10",
+    "fp64_int8_11", "fp64_int8_12", "fp64_int8_13", "fp64_int8_14", "fp64_int8_15",
+    "fp64_int8_16", "fp64_int8_17", "fp64_int8_18", "fp64_int8_auto"};
+
+int num_split_of_mode(ozimmu_compute_mode_t mode) { // src/config.cu:28-80
+  if (mode >= OZIMMU_FP64_INT8_3 && mode <= OZIMMU_FP64_INT8_18) return (int)mode - (int)OZIMMU_FP64_INT8_3 + 3;
+  return 0;
+}
+bool is_int8_mode(ozimmu_compute_mode_t mode) { return num_split_of_mode(mode) != 0; }
+
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+// largest K (multiple of 32) whose per-diagonal INT32 sums cannot overflow: at most S products of
+// magnitude <= (2^L-1)^2 per k.  (The reference bounds a single pair: k*2^(2L) <= 2^31, src/split.cu:520-536.)
+static size_t max_k_per_pass(int S, int L) {
+  const unsigned long long q = (1ull << L) - 1ull;
+  const unsigned long long kc = 2147483647ull / ((unsigned long long)S * q * q);
+  return (size_t)std::max<unsigned long long>(32ull, kc / 32ull * 32ull);
+}
+
+struct Workspace {
+  uint32_t *exps_a, *exps_b;
+  double *ea, *eb;
+  int8_t *planes_a, *planes_b;
+  double *acc;
+  size_t exps_bytes;
+  size_t total;
+};
+
+static Workspace carve(void *base, size_t m, size_t n, size_t k, int S, bool need_acc) {
+  Workspace w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void *p = base ? (void *)((char *)base + off) : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  w.exps_a = (uint32_t *)take(4 * m);
+  w.exps_b = (uint32_t *)take(4 * n);
+  w.exps_bytes = off; // exps_a and exps_b are adjacent: one memset
+  w.ea = (double *)take(8 * m);
+  w.eb = (double *)take(8 * n);
+  w.planes_a = (int8_t *)take(tiled_plane_bytes(m, k, S));
+  w.planes_b = (int8_t *)take(tiled_plane_bytes(n, k, S));
+  w.acc = need_acc ? (double *)take(8 * m * n) : nullptr;
+  w.total = off;
+  return w;
+}
+
+static bool needs_acc(size_t k, int S) {
+  const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k);
+  return S > SINGLE_PASS_MAX_S || k > max_k_per_pass(S, L);
+}
+
+static OperandView view_A(ozimmu_operation_t op, size_t m, size_t k, const double *a, size_t lda) {
+  // src/split.cu:254: col_major = (op == op_n): element (row, kk) at a[kk*lda + row]
+  return op == OZIMMU_OP_N ? OperandView{a, m, k, 1, lda} : OperandView{a, m, k, lda, 1};
+}
+static OperandView view_B(ozimmu_operation_t op, size_t k, size_t n, const double *b, size_t ldb) {
+  // src/split.cu:277-281: op flipped, m <-> n swapped: rows = n
+  return op == OZIMMU_OP_N ? OperandView{b, n, k, ldb, 1} : OperandView{b, n, k, 1, ldb};
+}
+
+static bool hip_ok(hipError_t e, const char *what) {
+  if (e == hipSuccess) return true;
+  log_error(std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
+  return false;
+}
+
+// src/utils.hpp:143-168
+static int check_gemm_shape(ozimmu_operation_t op, size_t m, size_t n, size_t ld, const char *mat) {
+  if ((op == OZIMMU_OP_N ? m : n) > ld) {
+    log_error(std::string("The leading dimension of ") + mat + " (" + std::to_string(ld) +
+              ") must be larger or equal to the number of " + (op == OZIMMU_OP_N ? "rows" : "cols") + " (" +
+              std::to_string(op == OZIMMU_OP_N ? m : n) + ")");
+    return 1;
+  }
+  return 0;
+}
+static int check_address_alignment(const void *p, size_t elem, const char *mat) {
+  if (reinterpret_cast<uintptr_t>(p) % elem) {
+    log_error(std::string("Invalid address alignment for matrix ") + mat);
+    return 1;
+  }
+  return 0;
+}
+
+// split of one operand into the workspace; stream ordered
+static bool run_split(ozimmu_hip_handle_t h, const OperandView &v, uint32_t *exps, int S, int L,
+                      int8_t *planes, double *max_exp) {
+  return hip_ok(launch_row_max_exp(v, exps, h->stream), "row_max_exp") &&
+         hip_ok(launch_cut(v, exps, S, L, planes, max_exp, h->stream), "cut");
+}
+
+static bool ensure_workspace(ozimmu_hip_handle_t h, size_t bytes) {
+  ozimmu_hip_reallocate_working_memory(h, bytes);
+  return h->working_memory_ptr != nullptr && h->current_working_memory_size >= bytes;
+}
+
+// gemm_int8<double> (src/gemm.cu:344-410), fused MI355X form.  dump != nullptr: test hook.
+static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                          size_t n, size_t k, double alpha, const double *a, size_t lda, const double *b,
+                          size_t ldb, double beta, double *c, size_t ldc, int S, int32_t *dump) {
+  const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/gemm.cu:357
+  const size_t kc = max_k_per_pass(S, L);
+  const bool acc_needed = needs_acc(k, S);
+  if (dump && k > kc) return 2; // whole-K INT32 sums would not be exact
+  Workspace sz = carve(nullptr, m, n, k, S, acc_needed);
+  if (!ensure_workspace(h, sz.total)) return 3;
+  Workspace w = carve(h->working_memory_ptr, m, n, k, S, acc_needed);
+
+  const bool prof = h->profiling;
+  if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
+  if (!hip_ok(hipMemsetAsync(w.exps_a, 0, w.exps_bytes, h->stream), "memset")) return 3;
+  if (!run_split(h, view_A(op_A, m, k, a, lda), w.exps_a, S, L, w.planes_a, w.ea)) return 3;
+  if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+  if (!run_split(h, view_B(op_B, k, n, b, ldb), w.exps_b, S, L, w.planes_b, w.eb)) return 3;
+  if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
+
+  SliceGemmArgs g{};
+  g.a_planes = w.planes_a;
+  g.b_planes = w.planes_b;
+  g.KB = (uint32_t)k_blocks(k);
+  g.M = (uint32_t)m;
+  g.N = (uint32_t)n;
+  g.tiles_m = (uint32_t)((m + TILE_ROWS - 1) / TILE_ROWS);
+  g.tiles_n = (uint32_t)((n + TILE_ROWS - 1) / TILE_ROWS);
+  g.L = L;
+  g.ea = w.ea;
+  g.eb = w.eb;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.c = c;
+  g.ldc = ldc;
+  g.acc = w.acc;
+  g.dump = dump;
+  g.dump_only = dump ? 1 : 0;
+  const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
+  for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
+    g.kb0 = kb0;
+    g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
+    g.acc_in = kb0 != 0;
+    g.final = g.kb1 == g.KB;
+    if (!hip_ok(launch_slice_gemm(S, g, h->stream), "slice_gemm")) return 3;
+  }
+  if (prof) {
+    if (!hip_ok(hipEventRecord(h->ev[3], h->stream), "event")) return 3;
+    if (!hip_ok(hipEventSynchronize(h->ev[3]), "event sync")) return 3; // reference: stop_timer_sync
+    for (int i = 0; i < 3; i++) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]);
+      h->stage_last_ms[i] = ms;
+      h->stage_total_ms[i] += ms;
+    }
+    h->stage_calls++;
+  }
+  return 0;
+}
+
+} // namespace ozhip
+
+// ---- C ABI ---------------------------------------------------------------------------------------------
+
+extern "C" {
+
+const char *ozimmu_hip_version(void) { return "ozimmu_hip 0.1 (gfx950)"; }
+
+uint32_t ozimmu_hip_get_bits_per_int8(uint32_t k) { // src/split.cu:520-536
+  if (k == 0) return 0;
+  uint32_t log2_k = 0; // ceil(log2(k))
+  while (log2_k < 31 && (1u << (log2_k + 1)) <= k) log2_k++;
+  if ((1u << log2_k) != k) log2_k++;
+  if (log2_k >= 31) return 0; // k > 2^30: the reference's unsigned (31 - log2_k) wraps; no slice width is safe
+  return std::min<uint32_t>(7, (31 - log2_k) / 2);
+}
+
+const char *ozimmu_hip_get_compute_mode_name_str(ozimmu_compute_mode_t mode) { // src/handle.cu:146-192
+  if ((int)mode < 0 || (int)mode > (int)OZIMMU_FP64_INT8_AUTO) return nullptr;
+  return kModeNames[(int)mode];
+}
+
+ozimmu_compute_mode_t ozimmu_hip_compute_mode_from_str(const char *name) { // src/cublas.cu:18-48
+  if (name)
+    for (int i = 0; i <= (int)OZIMMU_FP64_INT8_AUTO; i++)
+      if (std::strcmp(name, kModeNames[i]) == 0) return (ozimmu_compute_mode_t)i;
+  return OZIMMU_DGEMM;
+}
+
+int ozimmu_hip_get_num_split(ozimmu_compute_mode_t mode) { return num_split_of_mode(mode); }
+
+int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm) { // src/handle.cu:6-33
+  if (!handle) return 1;
+  log_info("Initializing ozIMMU handle");
+  ozimmu_hip_handle *h = new (std::nothrow) ozimmu_hip_handle;
+  if (!h) return 1;
+  h->malloc_mode = mm;
+  if (!hip_ok(hipMalloc((void **)&h->d_mantissa_loss_counter_ptr, sizeof(unsigned long long) * 16),
+              "hipMalloc(counters)")) {
+    delete h;
+    *handle = nullptr;
+    return 3;
+  }
+  for (auto &e : h->ev) hipEventCreate(&e);
+  auto read_thr = [](const char *name) -> uint32_t { // std::stoul in the reference (throws); here: default
+    const std::string s = load_env_if_defined(name, "1024");
+    char *end = nullptr;
+    const unsigned long v = std::strtoul(s.c_str(), &end, 10);
+    if (end == s.c_str()) {
+      log_error(std::string("Invalid value for ") + name + ": " + s + " (using 1024)");
+      return 1024u;
+    }
+    return (uint32_t)v;
+  };
+  h->intercept_threshold_m = read_thr("OZIMMU_INTERCEPT_THRESHOLD_M");
+  h->intercept_threshold_n = read_thr("OZIMMU_INTERCEPT_THRESHOLD_N");
+  h->intercept_threshold_k = read_thr("OZIMMU_INTERCEPT_THRESHOLD_K");
+  *handle = h;
+  return 0;
+}
+
+int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
+  if (h) {
+    log_info("Destroying ozIMMU handle");
+    if (h->rocblas_handle) {
+      auto destroy = (rocblas_status(*)(rocblas_handle))vendor_symbol("rocblas_destroy_handle");
+      if (destroy) destroy((rocblas_handle)h->rocblas_handle);
+    }
+    if (h->working_memory_ptr) hipFree(h->working_memory_ptr);
+    if (h->d_mantissa_loss_counter_ptr) hipFree(h->d_mantissa_loss_counter_ptr);
+    for (auto &e : h->ev)
+      if (e) hipEventDestroy(e);
+    delete h;
+  }
+  return 0;
+}
+
+void ozimmu_hip_set_stream(ozimmu_hip_handle_t h, void *hip_stream) { // src/handle.cu:54-61
+  if (h) h->stream = (hipStream_t)hip_stream;
+}
+
+void ozimmu_hip_enable_profiling(ozimmu_hip_handle_t h) {
+  if (h) h->profiling = true;
+}
+void ozimmu_hip_disable_profiling(ozimmu_hip_handle_t h) {
+  if (h) h->profiling = false;
+}
+void ozimmu_hip_clear_profiler_result(ozimmu_hip_handle_t h) {
+  if (!h) return;
+  for (auto &t : h->stage_total_ms) t = 0;
+  h->stage_calls = 0;
+}
+void ozimmu_hip_print_profiler_result(ozimmu_hip_handle_t h, const char *tag, int csv) {
+  if (!h) return;
+  // labels of the reference's breakdown (src/gemm.cu:38-48, src/config.cu:102-118, src/gemm.cu:393-407);
+  // accumulate_in_f64 and copy_result are fused into the int8tc kernel here and report 0.
+  static const char *labels[5] = {"split_A", "split_B", "int8tc", "accumulate_in_f64", "copy_result"};
+  const double t[5] = {h->stage_total_ms[0], h->stage_total_ms[1], h->stage_total_ms[2], 0.0, 0.0};
+  const double sum = t[0] + t[1] + t[2];
+  if (csv) {
+    std::printf("tag,label,calls,total_ms,share\n");
+    for (int i = 0; i < 5; i++)
+      std::printf("%s,%s,%llu,%.6f,%.4f\n", tag ? tag : "", labels[i], h->stage_calls, t[i],
+                  sum > 0 ? t[i] / sum : 0.0);
+  } else {
+    std::printf("# ozIMMU-HIP profiling result [%s] (%llu calls)\n", tag ? tag : "", h->stage_calls);
+    for (int i = 0; i < 5; i++)
+      std::printf("%20s : %12.4f ms (%6.2f%%)\n", labels[i], t[i], sum > 0 ? 100.0 * t[i] / sum : 0.0);
+  }
+  std::fflush(stdout);
+}
+int ozimmu_hip_last_stage_ms(ozimmu_hip_handle_t h, float ms[3]) {
+  if (!h || !ms) return 1;
+  for (int i = 0; i < 3; i++) ms[i] = h->stage_last_ms[i];
+  return 0;
+}
+
+void ozimmu_hip_set_auto_mantissa_loss_threashold(ozimmu_hip_handle_t h, double threshold) {
+  if (h) h->avg_mantissa_loss_threshold = threshold;
+}
+double ozimmu_hip_get_auto_mantissa_loss_threashold(ozimmu_hip_handle_t h) {
+  return h ? h->avg_mantissa_loss_threshold : 0.0;
+}
+
+size_t ozimmu_hip_reallocate_working_memory(ozimmu_hip_handle_t h, size_t size_in_byte) { // src/handle.cu:63-93
+  if (!h || size_in_byte <= h->current_working_memory_size) return 0;
+  log_info("Reallocated memory : " + std::to_string(size_in_byte) + " B");
+  if (h->working_memory_ptr) {
+    // kernels already enqueued on the stream still use the old block: release it in stream order
+    // (hipFree would device-synchronise, src/handle.cu:71-75 does exactly that)
+    if (h->malloc_mode == OZIMMU_MALLOC_SYNC)
+      hipFree(h->working_memory_ptr);
+    else
+      hipFreeAsync(h->working_memory_ptr, h->stream);
+    h->working_memory_ptr = nullptr;
+    h->current_working_memory_size = 0;
+  }
+  hipError_t e = h->malloc_mode == OZIMMU_MALLOC_SYNC
+                     ? hipMalloc(&h->working_memory_ptr, size_in_byte)
+                     : hipMallocAsync(&h->working_memory_ptr, size_in_byte, h->stream);
+  if (!hip_ok(e, "workspace allocation")) {
+    h->working_memory_ptr = nullptr;
+    return 0;
+  }
+  h->current_working_memory_size = size_in_byte;
+  return size_in_byte;
+}
+
+size_t ozimmu_hip_working_memory_size(ozimmu_operation_t, ozimmu_operation_t, size_t m, size_t n, size_t k,
+                                      ozimmu_element_kind_t element_kind, ozimmu_compute_mode_t mode) {
+  int S = num_split_of_mode(mode);
+  if (mode == OZIMMU_FP64_INT8_AUTO) S = 18; // worst case of what auto may select
+  if (S == 0 || element_kind != OZIMMU_REAL) return 0;
+  return carve(nullptr, m, n, k, S, needs_acc(k, S)).total;
+}
+
+static rocblas_operation to_rocblas_op(ozimmu_operation_t op) {
+  return op == OZIMMU_OP_N ? rocblas_operation_none : rocblas_operation_transpose;
+}
+
+int ozimmu_hip_native_dgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                            size_t n, size_t k, const double *alpha, const double *a, size_t lda,
+                            const double *b, size_t ldb, const double *beta, double *c, size_t ldc) {
+  if (!h) return 1;
+  typedef rocblas_status (*create_t)(rocblas_handle *);
+  typedef rocblas_status (*set_stream_t)(rocblas_handle, hipStream_t);
+  typedef rocblas_status (*dgemm_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int,
+                                    rocblas_int, rocblas_int, const double *, const double *, rocblas_int,
+                                    const double *, rocblas_int, const double *, double *, rocblas_int);
+  static create_t create = (create_t)vendor_symbol("rocblas_create_handle");
+  static set_stream_t set_stream = (set_stream_t)vendor_symbol("rocblas_set_stream");
+  static dgemm_t dgemm = (dgemm_t)vendor_symbol("rocblas_dgemm");
+  if (!create || !set_stream || !dgemm) return (int)rocblas_status_internal_error;
+  if (!h->rocblas_handle) {
+    rocblas_handle rh = nullptr;
+    const rocblas_status st = create(&rh);
+    if (st != rocblas_status_success) return (int)st;
+    h->rocblas_handle = rh;
+  }
+  set_stream((rocblas_handle)h->rocblas_handle, h->stream);
+  return (int)dgemm((rocblas_handle)h->rocblas_handle, to_rocblas_op(op_A), to_rocblas_op(op_B),
+                    (rocblas_int)m, (rocblas_int)n, (rocblas_int)k, alpha, a, (rocblas_int)lda, b,
+                    (rocblas_int)ldb, beta, c, (rocblas_int)ldc);
+}
+
+int ozimmu_hip_mantissa_loss(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                             size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb,
+                             uint64_t counters[16]) {
+  if (!h || !counters) return 1;
+  std::lock_guard<std::mutex> lock(h->mtx);
+  const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/split.cu:461
+  const size_t exps_bytes = align256(4 * m) + align256(4 * n);
+  if (!ensure_workspace(h, exps_bytes)) return 3;
+  uint32_t *exps_a = (uint32_t *)h->working_memory_ptr;
+  uint32_t *exps_b = (uint32_t *)((char *)h->working_memory_ptr + align256(4 * m));
+  const OperandView va = view_A(op_A, m, k, a, lda), vb = view_B(op_B, k, n, b, ldb);
+  bool ok = hip_ok(hipMemsetAsync(exps_a, 0, exps_bytes, h->stream), "memset") &&
+            hip_ok(hipMemsetAsync(h->d_mantissa_loss_counter_ptr, 0, 16 * sizeof(unsigned long long), h->stream),
+                   "memset") && // all 16 zeroed (src/split.cu:302-315 zeroes 8)
+            hip_ok(launch_row_max_exp(va, exps_a, h->stream), "row_max_exp") &&
+            hip_ok(launch_row_max_exp(vb, exps_b, h->stream), "row_max_exp") &&
+            hip_ok(launch_mantissa_loss(va, exps_a, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss") &&
+            hip_ok(launch_mantissa_loss(vb, exps_b, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss");
+  if (!ok) return 3;
+  unsigned long long host[16];
+  // blocking download, as src/split.cu:404-408
+  if (!hip_ok(hipMemcpyAsync(host, h->d_mantissa_loss_counter_ptr, sizeof(host), hipMemcpyDeviceToHost,
+                             h->stream),
+              "memcpy") ||
+      !hip_ok(hipStreamSynchronize(h->stream), "sync"))
+    return 3;
+  for (int i = 0; i < 16; i++) counters[i] = host[i];
+  return 0;
+}
+
+ozimmu_compute_mode_t ozimmu_hip_auto_mode_select(ozimmu_hip_handle_t h, ozimmu_operation_t op_A,
+                                                  ozimmu_operation_t op_B, size_t m, size_t n, size_t k,
+                                                  const void *a, size_t lda, const void *b, size_t ldb,
+                                                  ozimmu_element_kind_t element_kind, double threshold) {
+  if (!h || element_kind != OZIMMU_REAL) return OZIMMU_DGEMM;
+  uint64_t cnt[16];
+  if (ozimmu_hip_mantissa_loss(h, op_A, op_B, m, n, k, (const double *)a, lda, (const double *)b, ldb, cnt))
+    return OZIMMU_DGEMM;
+  const double denom = (double)(m * k + k * n); // src/split.cu:486
+  for (int s = 3; s <= 18; s++)
+    if ((double)cnt[s - 3] / denom <= threshold) return (ozimmu_compute_mode_t)((int)OZIMMU_FP64_INT8_3 + s - 3);
+  return OZIMMU_DGEMM; // src/split.cu:493
+}
+
+int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m, size_t n,
+                    size_t k, const void *alpha, const void *a, size_t lda, const void *b, size_t ldb,
+                    const void *beta, void *c, size_t ldc, ozimmu_compute_mode_t mode,
+                    ozimmu_element_kind_t element_kind) {
+  if (!h) return 1;
+  // src/gemm.cu:535-556
+  int arg_error = 0;
+  arg_error |= check_gemm_shape(op_A, m, k, lda, "A");
+  arg_error |= check_gemm_shape(op_B, k, n, ldb, "B");
+  arg_error |= check_gemm_shape(OZIMMU_OP_N, m, n, ldc, "C");
+  const size_t elem = element_kind == OZIMMU_REAL ? 8 : 16;
+  arg_error |= check_address_alignment(a, elem, "A");
+  arg_error |= check_address_alignment(b, elem, "B");
+  arg_error |= check_address_alignment(c, elem, "B"); // sic: the reference labels C as "B" too
+  if (arg_error) return 1;
+  if ((int)mode < 0 || (int)mode > (int)OZIMMU_FP64_INT8_AUTO) {
+    log_error("Not implemented (unknown compute mode)"); // OZIMMU_NOT_IMPLEMENTED throws in the reference
+    return 2;
+  }
+  if (element_kind != OZIMMU_REAL) {
+    log_error("complex (ZGEMM) Ozaki path is not implemented in this build");
+    return 2;
+  }
+  if (m == 0 || n == 0) return 0;
+
+  if (mode == OZIMMU_FP64_INT8_AUTO) { // src/gemm.cu:628-638
+    const ozimmu_compute_mode_t auto_mode = ozimmu_hip_auto_mode_select(
+        h, op_A, op_B, m, n, k, a, lda, b, ldb, element_kind, h->avg_mantissa_loss_threshold);
+    log_info(std::string("AUTO selected mode = ") + ozimmu_hip_get_compute_mode_name_str(auto_mode) +
+             ", threshold average mantissa loss = " + std::to_string(h->avg_mantissa_loss_threshold));
+    return ozimmu_hip_gemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, auto_mode, element_kind);
+  }
+  const int S = num_split_of_mode(mode);
+  if (S == 0 || k == 0) {
+    // `dgemm` (src/gemm.cu:639-645); `sgemm` (FP32 emulation, out of scope) and k == 0 also go native
+    const int st = ozimmu_hip_native_dgemm(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a,
+                                           lda, (const double *)b, ldb, (const double *)beta, (double *)c, ldc);
+    return st == 0 ? 0 : 3;
+  }
+  std::lock_guard<std::mutex> lock(h->mtx);
+  return gemm_int8_real(h, op_A, op_B, m, n, k, *(const double *)alpha, (const double *)a, lda,
+                        (const double *)b, ldb, *(const double *)beta, (double *)c, ldc, S, nullptr);
+}
+
+int ozimmu_hip_diagonal_sums(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                             size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb,
+                             unsigned num_split, int32_t *out) {
+  if (!h || !out || num_split < 3 || num_split > 18 || m == 0 || n == 0 || k == 0) return 1;
+  if (check_gemm_shape(op_A, m, k, lda, "A") | check_gemm_shape(op_B, k, n, ldb, "B")) return 1;
+  std::lock_guard<std::mutex> lock(h->mtx);
+  return gemm_int8_real(h, op_A, op_B, m, n, k, 1.0, a, lda, b, ldb, 0.0, nullptr, m, (int)num_split, out);
+}
+
+int ozimmu_hip_split_int8(ozimmu_hip_handle_t h, int8_t *out_ptr, uint32_t ldo, double *max_exp_ptr, size_t m,
+                          size_t n, const double *in_ptr, size_t ld, ozimmu_operation_t op,
+                          ozimmu_matrix_t matrix, unsigned num_split, unsigned bits_per_int8) {
+  if (!h || !out_ptr || !max_exp_ptr || num_split < 1 || num_split > 18 || bits_per_int8 < 1 || bits_per_int8 > 7)
+    return 1;
+  // src/split.cu:274-282: A: (m x n) = (rows x k) of op(A); B: (m x n) = (k x cols) of op(B)
+  const OperandView v = matrix == OZIMMU_MATRIX_A ? view_A(op, m, n, in_ptr, ld) : view_B(op, m, n, in_ptr, ld);
+  if (ldo < v.K) return 1;
+  if (v.rows == 0) return 0;
+  std::lock_guard<std::mutex> lock(h->mtx);
+  const size_t exps_bytes = align256(4 * v.rows);
+  const size_t plane_bytes = tiled_plane_bytes(v.rows, v.K, (int)num_split);
+  if (!ensure_workspace(h, exps_bytes + plane_bytes + 256)) return 3;
+  uint32_t *exps = (uint32_t *)h->working_memory_ptr;
+  int8_t *planes = (int8_t *)h->working_memory_ptr + exps_bytes;
+  bool ok = hip_ok(hipMemsetAsync(exps, 0, exps_bytes, h->stream), "memset");
+  if (v.K == 0) // nothing to cut: max_exp of an empty row is 0
+    ok = ok && hip_ok(hipMemsetAsync(max_exp_ptr, 0, 8 * v.rows, h->stream), "memset");
+  ok = ok && run_split(h, v, exps, (int)num_split, (int)bits_per_int8, planes, max_exp_ptr) &&
+       hip_ok(launch_untile(planes, v.rows, v.K, (int)num_split, out_ptr, ldo, h->stream), "untile");
+  return ok ? 0 : 3;
+}
+
+} // extern "C"

@@ -1,0 +1,77 @@
+// handle.h — library state shared by api.cpp (direct API) and interpose.cpp (LD_PRELOAD boundary).
+// Mirrors /root/reference/src/handle.hpp:6-31 (struct mtk::ozimmu::handle).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+
+#include "../../include/ozimmu_hip.h"
+
+struct ozimmu_hip_handle {
+  hipStream_t stream = nullptr;
+
+  // grow-only device workspace (src/handle.hpp:12-13, src/handle.cu:63-93)
+  void *working_memory_ptr = nullptr;
+  size_t current_working_memory_size = 0;
+  ozimmu_malloc_mode_t malloc_mode = OZIMMU_MALLOC_SYNC;
+
+  // auto mode: 16 counters for S = 3..18 (the reference allocates 8: src/handle.hpp:22)
+  unsigned long long *d_mantissa_loss_counter_ptr = nullptr;
+  double avg_mantissa_loss_threshold = 0; // src/handle.hpp:26
+
+  // src/handle.hpp:28-30, read at creation (src/handle.cu:25-30)
+  uint32_t intercept_threshold_m = 1024;
+  uint32_t intercept_threshold_n = 1024;
+  uint32_t intercept_threshold_k = 1024;
+
+  // stage breakdown (src/handle.hpp:16: cutf time_breakdown profiler; labels src/gemm.cu:38-48, :393-407)
+  bool profiling = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double stage_total_ms[3] = {0, 0, 0};
+  float stage_last_ms[3] = {0, 0, 0};
+  unsigned long long stage_calls = 0;
+
+  // private vendor BLAS handle for the `dgemm` mode (src/handle.hpp:8), created lazily
+  void *rocblas_handle = nullptr;
+
+  std::mutex mtx; // the reference is not thread safe (one unguarded global handle, src/cublas.cu:58)
+};
+
+namespace ozhip {
+
+// ---- env + logging (src/utils.hpp:77-115) ------------------------------------------------------------
+inline std::string load_env_if_defined(const char *name, const char *default_v = "") {
+  const char *e = getenv(name);
+  return e ? std::string(e) : std::string(default_v);
+}
+inline bool env_enabled(const char *name, bool default_v) {
+  const char *e = getenv(name);
+  return (e != nullptr && std::string(e) != "0") || (e == nullptr && default_v);
+}
+inline void log_info(const std::string &s) { // ozIMMU_log
+  if (env_enabled("OZIMMU_INFO", false)) {
+    std::fprintf(stdout, "[ozIMMU LOG] %s\n", s.c_str());
+    std::fflush(stdout);
+  }
+}
+inline void log_error(const std::string &s) { // ozIMMU_error: on unless OZIMMU_ERROR=0
+  if (env_enabled("OZIMMU_ERROR", true)) {
+    std::fprintf(stdout, "[ozIMMU ERROR] %s\n", s.c_str());
+    std::fflush(stdout);
+  }
+}
+
+// original vendor symbol: dlsym(RTLD_NEXT) first (preload case, src/utils.hpp:117-141), then the
+// already-loaded / default librocblas / libhipblas (direct-API case)
+void *vendor_symbol(const char *name);
+
+// mode helpers
+int num_split_of_mode(ozimmu_compute_mode_t mode);
+bool is_int8_mode(ozimmu_compute_mode_t mode);
+
+} // namespace ozhip

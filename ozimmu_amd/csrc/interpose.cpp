@@ -1,0 +1,346 @@
+// interpose.cpp — the LD_PRELOAD drop-in boundary: rocBLAS / hipBLAS DGEMM entry points.
+//
+// Replaces the reference's cuBLAS hijack layer /root/reference/src/cublas.cu:103-513:
+//   cublasCreate_v2 / cublasDestroy_v2   (:104-131)  -> rocblas_create_handle / rocblas_destroy_handle
+//   cublasGemmEx                         (:133-278)  -> rocblas_gemm_ex, hipblasGemmEx (all-FP64 real case)
+//   cublasDgemm_v2                       (:280-295)  -> rocblas_dgemm, rocblas_dgemm_64, hipblasDgemm
+//   cublasDgemmStridedBatched            (:474-492)  -> rocblas_dgemm_strided_batched (sequential loop, :380-406)
+// Originals are found with dlsym(RTLD_NEXT) (src/utils.hpp:117-141).
+//
+// Documented deviations from the reference (SURVEY.md §8a "quirks"):
+//   * `n` is compared with OZIMMU_INTERCEPT_THRESHOLD_N (the reference compares it with _K, src/cublas.cu:145);
+//   * the global handle is created lazily on first use and never dereferenced when absent (:144);
+//   * it is released when the LAST vendor handle created through this shim is destroyed, not on any destroy (:117-126);
+//   * an internal failure falls back to the vendor routine instead of reporting SUCCESS (:215-219);
+//   * device pointer mode, out-of-place gemm_ex (C != D) and complex types are passed through untouched;
+//   * a thread-local guard keeps the shim from re-intercepting calls made underneath itself
+//     (hipBLAS -> rocBLAS, and this library's own native-DGEMM fallback).
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <hipblas/hipblas.h>
+#include <rocblas/rocblas.h>
+#include <time.h>
+
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "handle.h"
+
+using namespace ozhip;
+
+namespace {
+
+std::mutex g_mtx;
+ozimmu_hip_handle_t g_handle = nullptr; // src/cublas.cu:58
+std::atomic<int> g_live_vendor_handles{0};
+thread_local int t_depth = 0;
+
+struct DepthGuard {
+  DepthGuard() { ++t_depth; }
+  ~DepthGuard() { --t_depth; }
+};
+
+template <class F> F original(const char *name) {
+  return reinterpret_cast<F>(vendor_symbol(name));
+}
+
+// src/cublas.cu:18-48
+ozimmu_compute_mode_t get_compute_mode() { return ozimmu_hip_compute_mode_from_str(getenv("OZIMMU_COMPUTE_MODE")); }
+
+// src/cublas.cu:60-86
+ozimmu_hip_handle_t get_global_handle() {
+  std::lock_guard<std::mutex> lock(g_mtx);
+  if (!g_handle) {
+    const ozimmu_malloc_mode_t mm = env_enabled("OZIMMU_MALLOC_ASYNC", false) ? OZIMMU_MALLOC_ASYNC : OZIMMU_MALLOC_SYNC;
+    log_info("Initializing ozIMMU handle...");
+    if (ozimmu_hip_create(&g_handle, mm) != 0) {
+      g_handle = nullptr;
+      return nullptr;
+    }
+    log_info("Successfully initialized");
+  }
+  if (const char *thr = getenv("OZIMMU_AUTO_AVG_MANTISSA_LOSS_THRESHOLD")) {
+    char *end = nullptr;
+    const double v = std::strtod(thr, &end);
+    if (end == thr) // the reference throws std::runtime_error here (src/cublas.cu:75-82)
+      log_error(std::string("ERROR: invalid value [OZIMMU_AUTO_AVG_MANTISSA_LOSS_THRESHOLD = ") + thr + "]");
+    else
+      ozimmu_hip_set_auto_mantissa_loss_threashold(g_handle, v);
+  }
+  return g_handle;
+}
+
+bool culip_enabled() { // src/culip.cu:41-50
+  const char *v = getenv("OZIMMU_ENABLE_CULIP_PROFILING");
+  return v && std::string(v) != "0";
+}
+
+ozimmu_operation_t to_oz(rocblas_operation op) { // src/cublas.cu:50-56: every non-N is T
+  return op == rocblas_operation_none ? OZIMMU_OP_N : OZIMMU_OP_T;
+}
+const char *op_str(ozimmu_operation_t op) { return op == OZIMMU_OP_N ? "N" : "T"; }
+
+// The intercept predicate + the Ozaki path.  true = handled (C holds the result).
+bool try_ozaki(hipStream_t stream, bool host_pointer_mode, ozimmu_operation_t op_a, ozimmu_operation_t op_b,
+               long long m, long long n, long long k, const double *alpha, const double *A, long long lda,
+               const double *B, long long ldb, const double *beta, double *C, long long ldc) {
+  if (t_depth > 0) return false;
+  const ozimmu_compute_mode_t mode = get_compute_mode();
+  if (mode == OZIMMU_DGEMM || mode == OZIMMU_SGEMM) return false; // sgemm emulation: out of scope -> native
+  if (!host_pointer_mode || m < 0 || n < 0 || k < 0 || !alpha || !beta) return false;
+  ozimmu_hip_handle_t h = get_global_handle();
+  if (!h) return false;
+  // src/cublas.cu:143-148 (with the threshold_n fix)
+  if (!((unsigned long long)m >= h->intercept_threshold_m && (unsigned long long)n >= h->intercept_threshold_n &&
+        (unsigned long long)k >= h->intercept_threshold_k))
+    return false;
+  ozimmu_hip_set_stream(h, stream); // src/cublas.cu:149-151
+
+  const bool prof = culip_enabled();
+  timespec t0{}, t1{};
+  if (prof) { // src/culip.cu:19-39: stream sync, CLOCK_MONOTONIC
+    hipStreamSynchronize(stream);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+  }
+  int err;
+  {
+    DepthGuard guard; // auto mode may fall back to the vendor DGEMM underneath
+    err = ozimmu_hip_gemm(h, op_a, op_b, (size_t)m, (size_t)n, (size_t)k, alpha, A, (size_t)lda, B, (size_t)ldb,
+                          beta, C, (size_t)ldc, mode, OZIMMU_REAL);
+  }
+  if (prof) {
+    hipStreamSynchronize(stream);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const unsigned long ns =
+        ((long)t1.tv_sec - (long)t0.tv_sec) * 1000000000l + ((long)t1.tv_nsec - (long)t0.tv_nsec);
+    // src/cublas.cu:157-162 name format
+    std::printf("[CULiP Result][D%s-%s%s-m%lld-n%lld-k%lld] %luns\n", ozimmu_hip_get_compute_mode_name_str(mode),
+                op_str(op_a), op_str(op_b), m, n, k, ns);
+    std::fflush(stdout);
+  }
+  if (err) log_error("Ozaki path failed (status " + std::to_string(err) + "); falling back to the vendor DGEMM");
+  return err == 0;
+}
+
+bool rocblas_ctx(rocblas_handle handle, hipStream_t *stream, bool *host_mode) {
+  typedef rocblas_status (*get_stream_t)(rocblas_handle, hipStream_t *);
+  typedef rocblas_status (*get_pm_t)(rocblas_handle, rocblas_pointer_mode *);
+  static get_stream_t get_stream = original<get_stream_t>("rocblas_get_stream");
+  static get_pm_t get_pm = original<get_pm_t>("rocblas_get_pointer_mode");
+  if (!handle || !get_stream || !get_pm) return false;
+  rocblas_pointer_mode pm = rocblas_pointer_mode_host;
+  if (get_stream(handle, stream) != rocblas_status_success) return false;
+  if (get_pm(handle, &pm) != rocblas_status_success) return false;
+  *host_mode = pm == rocblas_pointer_mode_host;
+  return true;
+}
+
+bool hipblas_ctx(hipblasHandle_t handle, hipStream_t *stream, bool *host_mode) {
+  typedef hipblasStatus_t (*get_stream_t)(hipblasHandle_t, hipStream_t *);
+  typedef hipblasStatus_t (*get_pm_t)(hipblasHandle_t, hipblasPointerMode_t *);
+  static get_stream_t get_stream = original<get_stream_t>("hipblasGetStream");
+  static get_pm_t get_pm = original<get_pm_t>("hipblasGetPointerMode");
+  if (!handle || !get_stream || !get_pm) return false;
+  hipblasPointerMode_t pm = HIPBLAS_POINTER_MODE_HOST;
+  if (get_stream(handle, stream) != HIPBLAS_STATUS_SUCCESS) return false;
+  if (get_pm(handle, &pm) != HIPBLAS_STATUS_SUCCESS) return false;
+  *host_mode = pm == HIPBLAS_POINTER_MODE_HOST;
+  return true;
+}
+
+ozimmu_operation_t hb_to_oz(hipblasOperation_t op) { return op == HIPBLAS_OP_N ? OZIMMU_OP_N : OZIMMU_OP_T; }
+
+} // namespace
+
+extern "C" {
+
+// ---- lifecycle (src/cublas.cu:104-131) -----------------------------------------------------------------
+
+rocblas_status rocblas_create_handle(rocblas_handle *handle) {
+  typedef rocblas_status (*fn_t)(rocblas_handle *);
+  static fn_t fn = original<fn_t>("rocblas_create_handle");
+  if (!fn) return rocblas_status_internal_error;
+  const rocblas_status st = fn(handle);
+  if (st == rocblas_status_success && t_depth == 0) {
+    g_live_vendor_handles++;
+    // the reference pre-sizes the workspace for a 1024^3 fp64_int8_9 GEMM here (src/cublas.cu:12-16, :109-110)
+    if (get_compute_mode() != OZIMMU_DGEMM)
+      if (ozimmu_hip_handle_t h = get_global_handle())
+        ozimmu_hip_reallocate_working_memory(
+            h, ozimmu_hip_working_memory_size(OZIMMU_OP_N, OZIMMU_OP_N, 1024, 1024, 1024, OZIMMU_REAL,
+                                              OZIMMU_FP64_INT8_9));
+  }
+  return st;
+}
+
+rocblas_status rocblas_destroy_handle(rocblas_handle handle) {
+  typedef rocblas_status (*fn_t)(rocblas_handle);
+  static fn_t fn = original<fn_t>("rocblas_destroy_handle");
+  if (!fn) return rocblas_status_internal_error;
+  if (t_depth == 0 && g_live_vendor_handles.fetch_sub(1) == 1) {
+    std::lock_guard<std::mutex> lock(g_mtx);
+    if (g_handle) {
+      log_info("Destroying ozIMMU handle...");
+      hipDeviceSynchronize(); // the workspace may still be in use by enqueued work
+      DepthGuard guard;       // ozimmu_hip_destroy releases its private vendor handle through this shim
+      ozimmu_hip_destroy(g_handle);
+      g_handle = nullptr;
+    }
+  }
+  return fn(handle);
+}
+
+// ---- rocBLAS -------------------------------------------------------------------------------------------
+
+rocblas_status rocblas_dgemm(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB,
+                             rocblas_int m, rocblas_int n, rocblas_int k, const double *alpha, const double *A,
+                             rocblas_int lda, const double *B, rocblas_int ldb, const double *beta, double *C,
+                             rocblas_int ldc) {
+  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                 rocblas_int, const double *, const double *, rocblas_int, const double *,
+                                 rocblas_int, const double *, double *, rocblas_int);
+  static fn_t fn = original<fn_t>("rocblas_dgemm");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  if (t_depth == 0 && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A, lda, B, ldb, beta, C, ldc))
+    return rocblas_status_success;
+  if (!fn) return rocblas_status_internal_error;
+  DepthGuard guard;
+  return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+rocblas_status rocblas_dgemm_64(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB,
+                                int64_t m, int64_t n, int64_t k, const double *alpha, const double *A, int64_t lda,
+                                const double *B, int64_t ldb, const double *beta, double *C, int64_t ldc) {
+  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, int64_t, int64_t, int64_t,
+                                 const double *, const double *, int64_t, const double *, int64_t, const double *,
+                                 double *, int64_t);
+  static fn_t fn = original<fn_t>("rocblas_dgemm_64");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  // the fused kernel indexes rows/columns with 32 bits
+  const bool fits = m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 30);
+  if (t_depth == 0 && fits && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A, lda, B, ldb, beta, C, ldc))
+    return rocblas_status_success;
+  if (!fn) return rocblas_status_internal_error;
+  DepthGuard guard;
+  return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+rocblas_status rocblas_gemm_ex(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB,
+                               rocblas_int m, rocblas_int n, rocblas_int k, const void *alpha, const void *a,
+                               rocblas_datatype a_type, rocblas_int lda, const void *b, rocblas_datatype b_type,
+                               rocblas_int ldb, const void *beta, const void *c, rocblas_datatype c_type,
+                               rocblas_int ldc, void *d, rocblas_datatype d_type, rocblas_int ldd,
+                               rocblas_datatype compute_type, rocblas_gemm_algo algo, int32_t solution_index,
+                               uint32_t flags) {
+  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                 rocblas_int, const void *, const void *, rocblas_datatype, rocblas_int, const void *,
+                                 rocblas_datatype, rocblas_int, const void *, const void *, rocblas_datatype,
+                                 rocblas_int, void *, rocblas_datatype, rocblas_int, rocblas_datatype,
+                                 rocblas_gemm_algo, int32_t, uint32_t);
+  static fn_t fn = original<fn_t>("rocblas_gemm_ex");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  // src/cublas.cu:146-148: all operands FP64 real; in place only (C == D)
+  const bool f64 = a_type == rocblas_datatype_f64_r && b_type == rocblas_datatype_f64_r &&
+                   c_type == rocblas_datatype_f64_r && d_type == rocblas_datatype_f64_r &&
+                   compute_type == rocblas_datatype_f64_r && c == d && ldc == ldd;
+  if (t_depth == 0 && f64 && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, (const double *)alpha, (const double *)a,
+                lda, (const double *)b, ldb, (const double *)beta, (double *)d, ldd))
+    return rocblas_status_success;
+  if (!fn) return rocblas_status_internal_error;
+  DepthGuard guard;
+  return fn(handle, transA, transB, m, n, k, alpha, a, a_type, lda, b, b_type, ldb, beta, c, c_type, ldc, d, d_type,
+            ldd, compute_type, algo, solution_index, flags);
+}
+
+rocblas_status rocblas_dgemm_strided_batched(rocblas_handle handle, rocblas_operation transA,
+                                             rocblas_operation transB, rocblas_int m, rocblas_int n, rocblas_int k,
+                                             const double *alpha, const double *A, rocblas_int lda,
+                                             rocblas_stride stride_a, const double *B, rocblas_int ldb,
+                                             rocblas_stride stride_b, const double *beta, double *C, rocblas_int ldc,
+                                             rocblas_stride stride_c, rocblas_int batch_count) {
+  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                 rocblas_int, const double *, const double *, rocblas_int, rocblas_stride,
+                                 const double *, rocblas_int, rocblas_stride, const double *, double *, rocblas_int,
+                                 rocblas_stride, rocblas_int);
+  static fn_t fn = original<fn_t>("rocblas_dgemm_strided_batched");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  if (t_depth == 0 && batch_count > 0 && get_compute_mode() != OZIMMU_DGEMM &&
+      rocblas_ctx(handle, &stream, &host_mode)) {
+    // sequential loop over the batch like src/cublas.cu:380-406; all-or-nothing on the first matrix
+    int done = 0;
+    for (; done < batch_count; done++)
+      if (!try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A + (size_t)done * stride_a, lda,
+                     B + (size_t)done * stride_b, ldb, beta, C + (size_t)done * stride_c, ldc))
+        break;
+    if (done == batch_count) return rocblas_status_success;
+    if (done > 0) { // finish the remainder natively, one matrix at a time
+      typedef rocblas_status (*dg_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                     rocblas_int, const double *, const double *, rocblas_int, const double *,
+                                     rocblas_int, const double *, double *, rocblas_int);
+      static dg_t dg = original<dg_t>("rocblas_dgemm");
+      if (!dg) return rocblas_status_internal_error;
+      DepthGuard guard;
+      for (; done < batch_count; done++) {
+        const rocblas_status st = dg(handle, transA, transB, m, n, k, alpha, A + (size_t)done * stride_a, lda,
+                                     B + (size_t)done * stride_b, ldb, beta, C + (size_t)done * stride_c, ldc);
+        if (st != rocblas_status_success) return st;
+      }
+      return rocblas_status_success;
+    }
+  }
+  if (!fn) return rocblas_status_internal_error;
+  DepthGuard guard;
+  return fn(handle, transA, transB, m, n, k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c,
+            batch_count);
+}
+
+// ---- hipBLAS (only reached when an application binds hipBLAS statically or resolves these first) --------
+
+hipblasStatus_t hipblasDgemm(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m,
+                             int n, int k, const double *alpha, const double *AP, int lda, const double *BP, int ldb,
+                             const double *beta, double *CP, int ldc) {
+  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                  const double *, const double *, int, const double *, int, const double *, double *,
+                                  int);
+  static fn_t fn = original<fn_t>("hipblasDgemm");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  if (t_depth == 0 && get_compute_mode() != OZIMMU_DGEMM && hipblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP, lda, BP, ldb, beta, CP,
+                ldc))
+    return HIPBLAS_STATUS_SUCCESS;
+  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
+  // no DepthGuard: the vendor hipblasDgemm calls rocblas_dgemm, which is the normal intercept point
+  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, BP, ldb, beta, CP, ldc);
+}
+
+hipblasStatus_t hipblasGemmEx(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m,
+                              int n, int k, const void *alpha, const void *A, hipDataType aType, int lda,
+                              const void *B, hipDataType bType, int ldb, const void *beta, void *C, hipDataType cType,
+                              int ldc, hipblasComputeType_t computeType, hipblasGemmAlgo_t algo) {
+  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                  const void *, const void *, hipDataType, int, const void *, hipDataType, int,
+                                  const void *, void *, hipDataType, int, hipblasComputeType_t, hipblasGemmAlgo_t);
+  static fn_t fn = original<fn_t>("hipblasGemmEx");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  const bool f64 = aType == HIP_R_64F && bType == HIP_R_64F && cType == HIP_R_64F && computeType == HIPBLAS_COMPUTE_64F;
+  if (t_depth == 0 && f64 && get_compute_mode() != OZIMMU_DGEMM && hipblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, (const double *)alpha,
+                (const double *)A, lda, (const double *)B, ldb, (const double *)beta, (double *)C, ldc))
+    return HIPBLAS_STATUS_SUCCESS;
+  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
+  return fn(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType,
+            algo);
+}
+
+} // extern "C"

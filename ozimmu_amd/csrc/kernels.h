@@ -1,0 +1,56 @@
+// kernels.h — launch interface between the host pipeline (api.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ozhip {
+
+constexpr int SINGLE_PASS_MAX_S = 10; // register budget: 16*S accumulators + 4*S B-fragments <= ~210 VGPRs
+
+struct SliceGemmArgs {
+  const int8_t *a_planes; // tiled planes of op(A): rows = M (layout.h)
+  const int8_t *b_planes; // tiled planes of op(B): rows = N
+  uint32_t KB;            // k-blocks per row-block in the planes
+  uint32_t kb0, kb1;      // k-block range of this pass (INT32-overflow chunking)
+  uint32_t M, N;
+  uint32_t tiles_m, tiles_n; // 64x64 output tiles
+  int L;                     // bits per slice (get_bits_per_int8)
+  const double *ea;          // [M] 2^(e_max+1) per row of op(A)
+  const double *eb;          // [N] per column of op(B)
+  double alpha, beta;
+  double *c;
+  size_t ldc;
+  double *acc; // [N][M] FP64 partial sums (multi-pass only)
+  int acc_in;  // start the fma chain from acc instead of 0
+  int final;   // 1: scale + alpha/beta -> C; 0: -> acc
+  int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
+  int dump_only; // test hook: skip the FP64 epilogue
+};
+
+hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);
+
+// element (r, k) of the operand view lives at in[r * stride_r + k * stride_k]; exactly one stride is 1
+struct OperandView {
+  const double *in;
+  size_t rows, K;
+  size_t stride_r, stride_k;
+};
+
+// exps[r] = max over k of the biased exponent field (11 bits) of row r; exps must be zeroed first
+hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream);
+
+// slices -> tiled planes (layout.h) and max_exp[r] = 2^(e_max+1) (0 for zero rows, NaN for poisoned rows)
+hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, int8_t *planes,
+                      double *max_exp, hipStream_t stream);
+
+// tiled planes -> reference layout [S][rows][ldo] (test hook for ozimmu_hip_split_int8)
+hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int8_t *out, size_t ldo,
+                         hipStream_t stream);
+
+// auto mode: counters[s-3] += sum over elements of max(0, req - s*L), s = 3..18
+hipError_t launch_mantissa_loss(const OperandView &v, const uint32_t *exps, int L,
+                                unsigned long long *counters, hipStream_t stream);
+
+} // namespace ozhip

@@ -1,0 +1,38 @@
+// layout.h — HBM layout of the INT8 slice planes ("tiled planes") shared by the split kernels
+// (producer) and the slice-GEMM kernel (consumer).
+//
+// The reference stores every slice as a K-contiguous matrix [S][rows][pad4(K)]
+// (/root/reference/src/split.cu:206-221, src/utils.hpp:30-72).  On CDNA4 the consumer is
+// v_mfma_i32_32x32x32_i8, whose A/B operand for one wave is "lane l holds 16 consecutive k-bytes
+// of row (l & 31), k-half (l >> 5)".  The planes are therefore stored directly in that fragment
+// order, one 1 KiB "fragment block" per (32 rows x 32 k) tile and slice:
+//
+//   byte offset(row, k, s) = (((row/32) * KB + k/32) * S + s) * 1024     fragment block
+//                          + ((k/16) & 1) * 512                           k-half  (lane >> 5)
+//                          + (row & 31) * 16                              row     (lane & 31)
+//                          + (k & 15)
+//
+// so that (a) one wave-wide 16-byte-per-lane copy moves exactly one fragment block HBM -> LDS with a
+// linear LDS image (what global_load_lds requires), (b) the MFMA operand read is ds_read_b128 at
+// base + lane*16: contiguous, bank-conflict free, and (c) all S slices of a (row-block, k-block) are
+// adjacent, so a GEMM workgroup streams S KiB contiguous runs that advance linearly with k.
+// Rows are padded to a multiple of 64 and k to a multiple of 32 with zero slices.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace ozhip {
+
+constexpr int FRAG_ROWS = 32;    // rows per fragment block
+constexpr int FRAG_K = 32;       // k-bytes per fragment block
+constexpr int FRAG_BYTES = 1024; // FRAG_ROWS * FRAG_K
+constexpr int TILE_ROWS = 64;    // GEMM workgroup tile edge: row padding granularity
+
+inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+inline size_t row_blocks_padded(size_t rows) { return round_up(rows, TILE_ROWS) / FRAG_ROWS; }
+inline size_t k_blocks(size_t k) { return (k + FRAG_K - 1) / FRAG_K; }
+inline size_t tiled_plane_bytes(size_t rows, size_t k, int S) {
+  return row_blocks_padded(rows) * k_blocks(k) * (size_t)S * FRAG_BYTES;
+}
+
+} // namespace ozhip

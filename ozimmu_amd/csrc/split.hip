@@ -1,0 +1,336 @@
+// split.hip — FP64 -> S x INT8 mantissa slices (+ per-row exponent), and the auto-mode statistic.
+//
+// Restates, for gfx950, the reference's split path:
+//   get_exp_max_element   /root/reference/src/split.cu:13-67   (row max of the exponent field)
+//   cut_int8_core         src/split.cu:154-185                 (truncating bit-slice of the mantissa)
+//   split_int8_kernel     src/split.cu:193-242                 (layout, zero padding, max_exp store)
+//   calculate_mantissa_loss_core/kernel  src/split.cu:317-380  (auto mode statistic)
+//
+// MI355X design (HBM-bound byte work, no MFMA):
+//  * both memory layouts of an operand are read with the lanes of a half-wave on 32 consecutive
+//    doubles (256 B runs): row-contiguous operands directly, k-contiguous operands through an LDS
+//    transpose -- never the reference's stride-ld per-thread walk (src/split.cu:208-210);
+//  * the row maximum is a separate streaming pass (u32 atomicMax per row, 64-lane DPP/LDS reduction
+//    instead of the reference's hard-coded 32-lane shuffles, src/split.cu:35-57);
+//  * one wave cuts one 32x32 block and writes S fragment blocks of 1 KiB, 16 B per lane, straight in
+//    MFMA operand order (layout.h) -- S contiguous KiB per wave instead of S strided byte stores per
+//    thread (src/split.cu:176-184);
+//  * no device synchronisation (the reference calls cudaDeviceSynchronize per operand, :261).
+//
+// Algorithmic HBM bytes: (8 + S) per element (one read, S slice bytes); this implementation reads
+// the operand twice (row-max pass + cut pass): 16 + S.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "layout.h"
+
+namespace ozhip {
+
+static constexpr unsigned long long MANT_MASK = 0x000FFFFFFFFFFFFFull;
+
+__device__ __forceinline__ unsigned exp_field(double x) {
+  return (unsigned)((unsigned long long)__double_as_longlong(x) >> 52) & 0x7FFu;
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// ---- pass 1: per-row maximum exponent field ---------------------------------------------------------
+// k-contiguous operand: element (r,k) at in[r*ld + k].  One wave per row segment, lanes along k.
+__global__ __launch_bounds__(256) void row_max_kcontig_kernel(const double *__restrict__ in, size_t rows,
+                                                              size_t K, size_t ld, uint32_t *exps,
+                                                              unsigned kchunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t r = (size_t)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const size_t k0 = (size_t)blockIdx.y * kchunk;
+  const size_t k1 = k0 + kchunk < K ? k0 + kchunk : K;
+  const double *p = in + r * ld;
+  unsigned e = 0;
+  size_t k = k0 + lane;
+  for (; k + 7 * 64 < k1; k += 8 * 64) {
+    unsigned t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = exp_field(p[k + u * 64]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) e = t[u] > e ? t[u] : e;
+  }
+  for (; k < k1; k += 64) {
+    const unsigned t = exp_field(p[k]);
+    e = t > e ? t : e;
+  }
+  e = wave_max_u32(e);
+  if (lane == 0 && e) atomicMax(exps + r, e);
+}
+
+// row-contiguous operand: element (r,k) at in[k*ld + r].  Lanes along r, the 4 waves interleave k.
+__global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__restrict__ in, size_t rows,
+                                                              size_t K, size_t ld, uint32_t *exps,
+                                                              unsigned kchunk) {
+  __shared__ unsigned red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t r = (size_t)blockIdx.x * 64 + lane;
+  const size_t k0 = (size_t)blockIdx.y * kchunk;
+  const size_t k1 = k0 + kchunk < K ? k0 + kchunk : K;
+  unsigned e = 0;
+  if (r < rows) {
+    const double *p = in + r;
+    size_t k = k0 + wave;
+    for (; k + 7 * 4 < k1; k += 8 * 4) {
+      unsigned t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = exp_field(p[(k + u * 4) * ld]);
+#pragma unroll
+      for (int u = 0; u < 8; u++) e = t[u] > e ? t[u] : e;
+    }
+    for (; k < k1; k += 4) {
+      const unsigned t = exp_field(p[k * ld]);
+      e = t > e ? t : e;
+    }
+  }
+  red[wave][lane] = e;
+  __syncthreads();
+  if (wave == 0) {
+    e = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; w++) e = red[w][lane] > e ? red[w][lane] : e;
+    if (r < rows && e) atomicMax(exps + r, e);
+  }
+}
+
+hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream) {
+  if (v.rows == 0 || v.K == 0) return hipSuccess;
+  if (v.stride_k == 1) {
+    const unsigned kchunk = 8192;
+    dim3 grid((unsigned)((v.rows + 3) / 4), (unsigned)((v.K + kchunk - 1) / kchunk));
+    hipLaunchKernelGGL(row_max_kcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
+                       v.stride_r, exps, kchunk);
+  } else {
+    const unsigned kchunk = 512;
+    dim3 grid((unsigned)((v.rows + 63) / 64), (unsigned)((v.K + kchunk - 1) / kchunk));
+    hipLaunchKernelGGL(row_max_rcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
+                       v.stride_k, exps, kchunk);
+  }
+  return hipGetLastError();
+}
+
+// ---- shared: load one 32 rows x 32 k block, lane (r = lane&31, kh = lane>>5) gets its 16 k values ---
+// Out-of-range rows / k read as +0.0 (-> zero slices: the padding the GEMM relies on).
+template <bool KCONTIG>
+__device__ __forceinline__ void load_block(const double *__restrict__ in, size_t rows, size_t K, size_t ld,
+                                           size_t rb, size_t kb, int lane, double (*tile)[33],
+                                           double v[16]) {
+  const int r = lane & 31, kh = lane >> 5;
+  if constexpr (!KCONTIG) {
+    const size_t rg = rb * 32 + r;
+    const size_t kbase = kb * 32 + kh * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const size_t k = kbase + q;
+      v[q] = (rg < rows && k < K) ? in[k * ld + rg] : 0.0;
+    }
+  } else {
+    // coalesced read: half-wave = 32 consecutive k of one row; 2 rows per instruction
+    const size_t k = kb * 32 + (lane & 31);
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int rr = it * 2 + (lane >> 5);
+      const size_t rg = rb * 32 + rr;
+      tile[rr][lane & 31] = (rg < rows && k < K) ? in[rg * ld + k] : 0.0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = tile[r][kh * 16 + q];
+  }
+}
+
+// ---- pass 2: cut ---------------------------------------------------------------------------------------
+template <bool KCONTIG>
+__global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in, size_t rows, size_t K,
+                                                  size_t ld, const uint32_t *__restrict__ exps, int S, int L,
+                                                  int8_t *__restrict__ planes, double *__restrict__ max_exp,
+                                                  size_t RB, size_t KB) {
+  __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t gw = (size_t)blockIdx.x * 4 + wave;
+  if (gw >= RB * KB) return;
+  // consecutive waves follow the memory-contiguous axis of the operand
+  const size_t rb = KCONTIG ? gw / KB : gw % RB;
+  const size_t kb = KCONTIG ? gw % KB : gw / RB;
+
+  double v[16];
+  load_block<KCONTIG>(in, rows, K, ld, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
+
+  const int r = lane & 31;
+  const size_t rg = rb * 32 + r;
+  const unsigned e = rg < rows ? exps[rg] : 0u;
+  // e == 0: zero/subnormal row -> max_exp 0, zero slices (reference: 0*2 = 0, src/split.cu:191)
+  // e >= 0x7FE: Inf/NaN in the row, or 2^(e+1) not representable -> poisoned row (max_exp = NaN)
+  const bool live = e != 0u && e < 0x7FEu;
+  if (kb == 0 && lane < 32 && rg < rows) {
+    const unsigned long long bits =
+        live ? ((unsigned long long)(e + 1) << 52) : (e == 0u ? 0ull : 0x7FF8000000000000ull);
+    max_exp[rg] = __longlong_as_double((long long)bits);
+  }
+
+  // 128-bit shifted mantissa (hi:lo) = (m53 << 75) >> off, per element (src/split.cu:163-175)
+  unsigned long long hi[16], lo[16];
+  unsigned negmask[4] = {0, 0, 0, 0}; // per packed word: 0xFF in the bytes of negative elements
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v[q]);
+    const unsigned f = (unsigned)(b >> 52) & 0x7FFu;
+    const unsigned long long m53 = (b & MANT_MASK) | (f ? (1ull << 52) : 0ull);
+    const unsigned ef = f ? f : 1u; // subnormal: exponent of field 1 (fix of SURVEY §8a quirk 7)
+    const unsigned off = e + 1u - ef; // >= 1 for live rows
+    const unsigned long long V = live ? (m53 << 11) : 0ull;
+    unsigned long long h, l;
+    if (off < 64u) {
+      h = V >> off;
+      l = V << (64u - off); // off >= 1
+    } else if (off < 128u) {
+      h = 0;
+      l = V >> (off - 64u);
+    } else {
+      h = 0;
+      l = 0;
+    }
+    hi[q] = h;
+    lo[q] = l;
+    if (b >> 63) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
+  }
+
+  const unsigned long long mask = (1ull << L) - 1ull;
+  int8_t *out = planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16;
+  for (int s = 0; s < S; s++) {
+    const int p = 128 - (s + 1) * L; // low bit of slice s inside (hi:lo); p >= 2 since S*L <= 126
+    unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      unsigned long long x;
+      if (p >= 64)
+        x = hi[q] >> (p - 64);
+      else
+        x = (lo[q] >> p) | (hi[q] << (64 - p));
+      w[q >> 2] |= (unsigned)(x & mask) << (8 * (q & 3));
+    }
+    uint4 o;
+    unsigned *op = &o.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      // per-byte two's complement of the bytes selected by negmask (values <= 127, SWAR, no carries)
+      const unsigned m = negmask[i], t = w[i] ^ m;
+      op[i] = ((t & 0x7F7F7F7Fu) + (m & 0x01010101u)) ^ (t & 0x80808080u);
+    }
+    *(uint4 *)(out + (size_t)s * FRAG_BYTES) = o;
+  }
+}
+
+hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, int8_t *planes,
+                      double *max_exp, hipStream_t stream) {
+  const size_t RB = row_blocks_padded(v.rows), KB = k_blocks(v.K);
+  if (RB * KB == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((RB * KB + 3) / 4);
+  if (v.stride_k == 1)
+    hipLaunchKernelGGL(cut_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r,
+                       exps, S, L, planes, max_exp, RB, KB);
+  else
+    hipLaunchKernelGGL(cut_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_k,
+                       exps, S, L, planes, max_exp, RB, KB);
+  return hipGetLastError();
+}
+
+// ---- test hook: tiled planes -> reference layout [S][rows][ldo] --------------------------------------
+__global__ void untile_kernel(const int8_t *__restrict__ planes, size_t rows, size_t K, int S,
+                              int8_t *__restrict__ out, size_t ldo, size_t KB) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)S * rows * ldo;
+  if (idx >= total) return;
+  const size_t k = idx % ldo, r = (idx / ldo) % rows, s = idx / (ldo * rows);
+  int8_t val = 0;
+  if (k < K) {
+    const size_t off = (((r / 32) * KB + k / 32) * (size_t)S + s) * FRAG_BYTES + ((k / 16) & 1) * 512 +
+                       (r & 31) * 16 + (k & 15);
+    val = planes[off];
+  }
+  out[idx] = val;
+}
+
+hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int8_t *out, size_t ldo,
+                         hipStream_t stream) {
+  const size_t total = (size_t)S * rows * ldo;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(untile_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, planes,
+                     rows, K, S, out, ldo, k_blocks(K));
+  return hipGetLastError();
+}
+
+// ---- auto mode: mantissa-loss statistic (src/split.cu:317-380) ---------------------------------------
+template <bool KCONTIG>
+__global__ __launch_bounds__(256) void mantissa_loss_kernel(const double *__restrict__ in, size_t rows,
+                                                            size_t K, size_t ld,
+                                                            const uint32_t *__restrict__ exps, int L,
+                                                            unsigned long long *counters, size_t RB,
+                                                            size_t KB) {
+  __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
+  __shared__ unsigned long long blk[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 16) blk[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t gw = (size_t)blockIdx.x * 4 + wave;
+  unsigned loss[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) loss[i] = 0;
+  if (gw < RB * KB) {
+    const size_t rb = KCONTIG ? gw / KB : gw % RB;
+    const size_t kb = KCONTIG ? gw % KB : gw / RB;
+    double v[16];
+    load_block<KCONTIG>(in, rows, K, ld, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
+    const size_t rg = rb * 32 + (lane & 31);
+    const unsigned e = rg < rows ? exps[rg] : 0u;
+    if (e != 0u && e != 0x7FFu) { // max_exp != 0 (src/split.cu:322); non-finite rows carry no statistic
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        if (v[q] == 0.0) continue; // src/split.cu:322
+        const unsigned req = (e + 1u - exp_field(v[q])) + 53u; // :325-329
+#pragma unroll
+        for (int s = 3; s <= 18; s++) { // :330-337
+          const unsigned space = (unsigned)(s * L);
+          loss[s - 3] += space < req ? req - space : 0u;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    unsigned x = loss[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    if (lane == 0 && x) atomicAdd(&blk[i], (unsigned long long)x);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && blk[threadIdx.x]) atomicAdd(counters + threadIdx.x, blk[threadIdx.x]);
+}
+
+hipError_t launch_mantissa_loss(const OperandView &v, const uint32_t *exps, int L,
+                                unsigned long long *counters, hipStream_t stream) {
+  const size_t RB = (v.rows + 31) / 32, KB = k_blocks(v.K);
+  if (RB * KB == 0) return hipSuccess;
+  const unsigned grid = (unsigned)((RB * KB + 3) / 4);
+  if (v.stride_k == 1)
+    hipLaunchKernelGGL(mantissa_loss_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K,
+                       v.stride_r, exps, L, counters, RB, KB);
+  else
+    hipLaunchKernelGGL(mantissa_loss_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K,
+                       v.stride_k, exps, L, counters, RB, KB);
+  return hipGetLastError();
+}
+
+} // namespace ozhip

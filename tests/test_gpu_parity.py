@@ -1,0 +1,238 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (task ③): bit-exact for the integer stages (slices, max_exp, INT32 diagonal sums) and for the FP64
+result against the oracle evaluated in the kernel's own summation grouping (OZ_ORDER_DIAGONAL); against
+the reference's pair-by-pair grouping (OZ_ORDER_REFERENCE) the FP64 result may differ only by the
+rounding of the regrouped sum -- tolerance stated in each test.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import ColMajor, exp_rand, operand, uniform01, uniform_pm1, wide_exponent
+
+pytestmark = pytest.mark.gpu
+
+OPS = ["N", "T"]
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------- split (rows A1-A5 of SURVEY §8a)
+
+@pytest.mark.parametrize("matrix", ["A", "B"])
+@pytest.mark.parametrize("op", OPS)
+@pytest.mark.parametrize("rows,k", [(1, 1), (5, 3), (33, 37), (64, 32), (70, 100), (130, 257)])
+@pytest.mark.parametrize("S", [3, 9, 18])
+def test_split_bit_exact(oz, matrix, op, rows, k, S):
+    import torch
+    m_, h = oz
+    rng = np.random.default_rng(1000 * rows + k + S)
+    L = O.bits_per_int8(k)
+    if matrix == "A":
+        x = operand(op, rows, k, rng, fill=wide_exponent(6), pad=3)
+        mm, nn = rows, k
+    else:
+        x = operand(op, k, rows, rng, fill=wide_exponent(6), pad=3)
+        mm, nn = k, rows
+    planes_ref, mx_ref = O.split(matrix, op, x.view, S, L)
+    ldo = O.pad4(k)
+    out = torch.full((S, rows, ldo), 77, dtype=torch.int8, device="cuda")
+    mx = torch.full((rows,), -1.0, dtype=torch.float64, device="cuda")
+    st = m_.split_int8(h, out, ldo, mx, mm, nn, x.dev, x.ld, op, m_.matrix_A if matrix == "A" else m_.matrix_B,
+                       S, L)
+    _sync()
+    assert st == 0
+    np.testing.assert_array_equal(mx.cpu().numpy().view(np.uint64), mx_ref.view(np.uint64))
+    np.testing.assert_array_equal(out.cpu().numpy(), planes_ref)
+
+
+def test_split_special_rows(oz):
+    """zero row, subnormal-only row, subnormal inside a tiny row, Inf row, NaN row, huge row, off >= 128"""
+    import torch
+    m_, h = oz
+    rng = np.random.default_rng(7)
+    rows, k, S = 40, 50, 12
+    a = operand("T", rows, k, rng)  # k-contiguous rows
+    v = a.view  # (k, rows) storage of A^T: column r is row r of op(A)
+    v[:, 0] = 0.0
+    v[:, 1] = 5e-324 * rng.integers(1, 1000, k)       # all subnormal -> max_exp 0, zero slices
+    v[:, 2] = 1e-300 * rng.uniform(-1, 1, k)          # tiny normal row ...
+    v[3, 2] = 3e-310                                  # ... with a subnormal element
+    v[5, 3] = np.inf
+    v[6, 4] = np.nan
+    v[:, 5] = rng.uniform(-1, 1, k) * 1e308           # near the top of the exponent range
+    v[0, 5] = 1.7e308                                 # exponent field 0x7FE -> poisoned (2^(e+1) overflows)
+    v[:, 6] = rng.uniform(-1, 1, k) * 1e-200
+    v[0, 6] = 1e100                                   # spread > 2^127: small elements vanish (shift >= 128)
+    v[:, 7] = -np.abs(v[:, 7])                        # all negative
+    v[2, 8] = -0.0
+    L = O.bits_per_int8(k)
+    planes_ref, mx_ref = O.split("A", "T", a.view, S, L)
+    out = torch.zeros((S, rows, O.pad4(k)), dtype=torch.int8, device="cuda")
+    mx = torch.zeros((rows,), dtype=torch.float64, device="cuda")
+    assert m_.split_int8(h, out, O.pad4(k), mx, rows, k, a.dev, a.ld, "T", m_.matrix_A, S, L) == 0
+    _sync()
+    got_mx = mx.cpu().numpy()
+    assert got_mx[0] == 0 and got_mx[1] == 0
+    assert np.isnan(got_mx[3]) and np.isnan(got_mx[4]) and np.isnan(got_mx[5])
+    np.testing.assert_array_equal(got_mx.view(np.uint64), mx_ref.view(np.uint64))
+    np.testing.assert_array_equal(out.cpu().numpy(), planes_ref)
+
+
+# ---------------------------------------------------------------- INT32 slice products (row A6)
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("m,n,k,S", [(64, 64, 32, 3), (100, 70, 130, 6), (65, 129, 257, 9), (33, 31, 65, 13),
+                                     (40, 50, 40, 18)])
+def test_diagonal_sums_bit_exact(oz, op_a, op_b, m, n, k, S):
+    import torch
+    m_, h = oz
+    rng = np.random.default_rng(m * 7 + n * 3 + k + S)
+    a = operand(op_a, m, k, rng, fill=exp_rand(2.0))
+    b = operand(op_b, k, n, rng, fill=exp_rand(2.0))
+    L = O.bits_per_int8(k)
+    pa, _ = O.split("A", op_a, a.view, S, L)
+    pb, _ = O.split("B", op_b, b.view, S, L)
+    d_ref = O.diagonal_sums(pa, pb)  # [S][m][n] int64
+    out = torch.full((S, n, m), 12345, dtype=torch.int32, device="cuda")
+    assert m_.diagonal_sums(h, op_a, op_b, m, n, k, a.dev, a.ld, b.dev, b.ld, S, out) == 0
+    _sync()
+    got = out.cpu().numpy().transpose(0, 2, 1).astype(np.int64)
+    np.testing.assert_array_equal(got, d_ref)
+
+
+# ---------------------------------------------------------------- full DGEMM (rows A7-A10)
+
+def _run_gemm(m_, h, op_a, op_b, m, n, k, alpha, a, b, beta, c, mode):
+    st = m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, mode)
+    _sync()
+    return st
+
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("m,n,k", [(64, 64, 64), (1, 1, 1), (3, 200, 5), (127, 65, 333), (256, 192, 1030)])
+@pytest.mark.parametrize("S", [3, 6, 9, 10, 11, 14, 18])
+def test_gemm_bit_exact_vs_oracle_diagonal_order(oz, op_a, op_b, m, n, k, S):
+    m_, h = oz
+    rng = np.random.default_rng(m + 2 * n + 3 * k + S)
+    a = operand(op_a, m, k, rng, pad=1)
+    b = operand(op_b, k, n, rng, pad=2)
+    c = ColMajor(m, n, ld=m + 5, fill=uniform_pm1, rng=rng)
+    c_ref = ColMajor(m, n, ld=m + 5)
+    c_ref.buf[...] = c.buf
+    mode = f"fp64_int8_{S}"
+    assert _run_gemm(m_, h, op_a, op_b, m, n, k, 1.0, a, b, 0.0, c, mode) == 0
+    assert O.gemm(op_a, op_b, m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    got = c.download()
+    np.testing.assert_array_equal(got.view(np.uint64), c_ref.view.view(np.uint64))
+    # the padding rows of C (ld > m) must be untouched (NaN poison survives)
+    assert np.isnan(c.buf[:, m:]).all()
+
+
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (-2.5, 0.0), (1.0, 1.0), (0.75, -1.25)])
+def test_gemm_alpha_beta(oz, alpha, beta):
+    m_, h = oz
+    m, n, k, S = 130, 70, 200, 9
+    rng = np.random.default_rng(5)
+    a = operand("N", m, k, rng)
+    b = operand("T", k, n, rng)
+    c = ColMajor(m, n, fill=uniform_pm1, rng=rng)
+    c_ref = ColMajor(m, n)
+    c_ref.buf[...] = c.buf
+    assert _run_gemm(m_, h, "N", "T", m, n, k, alpha, a, b, beta, c, "fp64_int8_9") == 0
+    assert O.gemm("N", "T", m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
+@pytest.mark.parametrize("S", [6, 8, 9, 12])
+def test_gemm_vs_reference_pair_order(oz, S):
+    """Against the reference's pair-by-pair FP64 accumulation (src/gemm.cu:385-403) the fused kernel
+    differs only by regrouping the same exact terms: |diff| <= 4 ulp of the largest partial sum, i.e.
+    <= 4 * 2^-52 * max|C| * 2 here, and the residual vs the long-double truth is not worse."""
+    m_, h = oz
+    m, n, k = 200, 150, 512
+    rng = np.random.default_rng(11)
+    a = operand("T", m, k, rng)
+    b = operand("N", k, n, rng)
+    c = ColMajor(m, n)
+    c_ref = ColMajor(m, n)
+    assert _run_gemm(m_, h, "T", "N", m, n, k, 1.0, a, b, 0.0, c, f"fp64_int8_{S}") == 0
+    O.gemm("T", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_REFERENCE)
+    got = c.download()
+    scale = np.abs(c_ref.view).max()
+    assert np.abs(got - c_ref.view).max() <= 8 * 2.0 ** -52 * scale
+    r_hip = O.relative_residual("T", "N", m, n, k, a.view, b.view, got)
+    r_ref = O.relative_residual("T", "N", m, n, k, a.view, b.view, c_ref.view)
+    assert r_hip <= 1.05 * r_ref + 1e-17
+
+
+def test_gemm_k_chunking_large_k(oz):
+    """K above the INT32-safe length per pass (S*K*127^2 < 2^31): two passes through the FP64 acc
+    workspace, same fma chain as the oracle with kchunk."""
+    m_, h = oz
+    m, n, k, S = 64, 64, 20000, 9
+    rng = np.random.default_rng(3)
+    a = operand("N", m, k, rng)
+    b = operand("N", k, n, rng)
+    c = ColMajor(m, n)
+    c_ref = ColMajor(m, n)
+    assert _run_gemm(m_, h, "N", "N", m, n, k, 1.0, a, b, 0.0, c, "fp64_int8_9") == 0
+    kchunk = (2147483647 // (S * 127 * 127)) // 32 * 32
+    O.gemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL, kchunk=kchunk)
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
+def test_gemm_argument_errors(oz):
+    """src/gemm.cu:535-556: bad leading dimension / misaligned pointer -> 1, nothing written"""
+    import torch
+    m_, h = oz
+    a = torch.zeros(64 * 64, dtype=torch.float64, device="cuda")
+    c = torch.full((64 * 64,), 3.0, dtype=torch.float64, device="cuda")
+    assert m_.gemm(h, "N", "N", 64, 64, 64, 1.0, a, 63, a, 64, 0.0, c, 64, "fp64_int8_6") == 1
+    assert m_.gemm(h, "T", "N", 64, 64, 32, 1.0, a, 16, a, 64, 0.0, c, 64, "fp64_int8_6") == 1
+    assert m_.gemm(h, "N", "N", 64, 64, 64, 1.0, a, 64, a, 64, 0.0, c, 10, "fp64_int8_6") == 1
+    assert m_.gemm(h, "N", "N", 64, 64, 64, 1.0, a.data_ptr() + 4, 64, a, 64, 0.0, c, 64, "fp64_int8_6") == 1
+    _sync()
+    assert (c == 3.0).all()
+
+
+# ---------------------------------------------------------------- the reference's own gate
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("mnk", [(1023, 1024, 1025), (1025, 1023, 1024), (1024, 1025, 1023)])
+@pytest.mark.parametrize("S", [8, 12, 16])
+def test_reference_ci_gate(oz, op_a, op_b, mnk, S):
+    """test/main_test.cu:702-746: urand01 inputs, alpha=1, beta=0, relative residual < 1e-15"""
+    m_, h = oz
+    m, n, k = mnk
+    rng = np.random.default_rng(0)
+    a = operand(op_a, m, k, rng, fill=uniform01)
+    b = operand(op_b, k, n, rng, fill=uniform01)
+    c = ColMajor(m, n)
+    assert _run_gemm(m_, h, op_a, op_b, m, n, k, 1.0, a, b, 0.0, c, f"fp64_int8_{S}") == 0
+    r = O.relative_residual_sampled(op_a, op_b, m, n, k, a.view, b.view, c.download(), ns=4096)
+    assert r < 1e-15
+
+
+# ---------------------------------------------------------------- auto mode (row A11)
+
+@pytest.mark.parametrize("fill,thr", [(uniform_pm1, 1.5), (wide_exponent(8), 1.5), (uniform_pm1, 0.0),
+                                      (wide_exponent(30), 0.0)])
+@pytest.mark.parametrize("op_a,op_b", [("N", "T"), ("T", "N")])
+def test_auto_mode_counters_and_selection(oz, fill, thr, op_a, op_b):
+    m_, h = oz
+    m, n, k = 150, 90, 300
+    rng = np.random.default_rng(21)
+    a = operand(op_a, m, k, rng, fill=fill)
+    b = operand(op_b, k, n, rng, fill=fill)
+    a.view[3, 4] = 0.0
+    s_ref, cnt_ref = O.auto_select(op_a, op_b, m, n, k, a.view, b.view, thr)
+    cnt = m_.mantissa_loss(h, op_a, op_b, m, n, k, a.dev, a.ld, b.dev, b.ld)
+    assert cnt == cnt_ref.tolist()
+    mode = m_.auto_mode_select(h, op_a, op_b, m, n, k, a.dev, a.ld, b.dev, b.ld, m_.real, thr)
+    expect = m_.dgemm if s_ref == 0 else m_.fp64_int8_3 + (s_ref - 3)
+    assert mode == expect
