@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark: DGEMM-equivalent TFLOP/s of the Ozaki-scheme DGEMM (fp64_int8_9,
+M=N=K=8192, U[-1,1) inputs, op N/N, alpha=1, beta=0) on MI355X, through the C ABI (ozimmu_hip_gemm).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--mode fp64_int8_9]
+
+A "step" is one whole DGEMM call (split A, split B, fused slice GEMM + recombination) on inputs already
+resident in HBM.  Timing protocol of the reference harness (test/main_test.cu:119-141): warm-up, then K
+back-to-back calls between device synchronisations; throughput = 2*M*N*K / t.  With --gpus N > 1 the job is
+N independent replicas (the path does not shard: DESIGN.md "Multi-GPU"), one process per GPU launched by
+torch.distributed.run; the only collective is the barrier / max-over-ranks of the timing contract.
+
+Prints ONE JSON line on rank 0 (fields: see the round contract); also carries
+  roofline      : the fused slice-GEMM kernel against the dense INT8 MFMA peak (HIP events on the
+                  library's stream around that kernel, measured live after the timed region)
+  cpu_baseline  : the CPU oracle (a plain-C port of the reference algorithm) on a bounded sample
+  extra         : relative residual, native rocBLAS DGEMM TFLOP/s, OpenBLAS DGEMM TFLOP/s on the host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+INT8_MFMA_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 1024 MAC/clk x 2 x 2.4 GHz (MI355X_MICROARCH.md: I8 = 2x bf16 dense 2.5 PF)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--n", type=int, default=8192, help="square size M=N=K (BASELINE.json configs[1])")
+    p.add_argument("--m", type=int, default=0)
+    p.add_argument("--k", type=int, default=0)
+    p.add_argument("--mode", default="fp64_int8_9")
+    p.add_argument("--opa", default="N")
+    p.add_argument("--opb", default="N")
+    p.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines (profiling runs)")
+    p.add_argument("--no-extra", action="store_true", help="skip residual / rocBLAS comparison")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import ozimmu_amd as oz  # after torch: one shared HIP runtime
+
+    N = args.n
+    M = args.m or N
+    K = args.k or N
+    S = oz.get_num_split(args.mode)
+    P = S * (S + 1) // 2
+    opa, opb = args.opa.upper(), args.opb.upper()
+
+    # synthetic inputs, seeded, generated on the device: U[-1,1) (BASELINE configs[1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    a_shape = (K, M) if opa == "N" else (M, K)   # torch row-major (cols, ld) == column-major storage
+    b_shape = (N, K) if opb == "N" else (K, N)
+    A = torch.rand(a_shape, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1
+    B = torch.rand(b_shape, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1
+    Cm = torch.zeros((N, M), dtype=torch.float64, device="cuda")
+    lda, ldb, ldc = a_shape[1], b_shape[1], M
+
+    h = oz.create()
+    stream = torch.cuda.current_stream()
+    oz.set_cuda_stream(h, stream)
+    oz.reallocate_working_memory(h, [(opa, opb, M, N, K, oz.real, args.mode)])
+
+    def step():
+        st = oz.gemm(h, opa, opb, M, N, K, 1.0, A, lda, B, ldb, 0.0, Cm, ldc, args.mode)
+        if st != 0:
+            raise RuntimeError(f"ozimmu_hip_gemm failed: {st}")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    flops_per_step = 2.0 * M * N * K
+    value = world * flops_per_step * args.steps / elapsed / 1e12
+    out = {
+        "metric": "DGEMM-equivalent TFLOP/s (2*M*N*K/t), Ozaki-scheme INT8 DGEMM",
+        "value": round(value, 3),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int8 slices of f64 (INT8xINT8->INT32 MFMA, FP64 recombination)",
+        "data": "synthetic",
+        "config": {"workload": f"{args.mode}, M={M} N={N} K={K}, op {opa}/{opb}, U[-1,1), alpha=1 beta=0",
+                   "parallelism": "replicas" if world > 1 else "single GPU",
+                   "slices": S, "slice_products": P},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events on the library's stream around the fused slice GEMM
+        oz.enable_profiling(h)
+        ms = []
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+            ms.append(oz.last_stage_ms(h))
+        oz.disable_profiling(h)
+        k_ms = float(np.mean([x["int8tc"] for x in ms]))
+        split_ms = float(np.mean([x["split_A"] + x["split_B"] for x in ms]))
+        int8_ops = P * 2.0 * M * N * K
+        achieved = int8_ops / (k_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "slice_gemm_kernel (INT8 MFMA slice products + FP64 recombination epilogue)",
+            "bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
+            "traffic": None,
+            "avg_kernel_ms": round(k_ms, 4),
+            "algorithmic_int8_ops_per_launch": int8_ops,
+            "split_ms": round(split_ms, 4),
+            "split_share_of_call": round(split_ms / (split_ms + k_ms), 4),
+            "split_algorithmic_GBps": round((8 + S) * (M * K + K * N) / (split_ms * 1e-3) / 1e9, 1),
+        }
+
+        if not args.no_extra:
+            from oracle import oracle as O
+            extra = {}
+            # residual vs long-double truth on sampled entries (mateval's relative_residual definition)
+            a_h = A.cpu().numpy().T  # column-major views (rows, cols), strides (8, 8*ld)
+            b_h = B.cpu().numpy().T
+            c_h = Cm.cpu().numpy().T
+            extra["relative_residual"] = O.relative_residual_sampled(opa, opb, M, N, K, a_h, b_h, c_h, ns=2048)
+            # native FP64 DGEMM (rocBLAS) on the same inputs
+            C2 = torch.zeros_like(Cm)
+            for _ in range(2):
+                oz.native_dgemm(h, opa, opb, M, N, K, 1.0, A, lda, B, ldb, 0.0, C2, ldc)
+            torch.cuda.synchronize()
+            reps = 5
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                oz.native_dgemm(h, opa, opb, M, N, K, 1.0, A, lda, B, ldb, 0.0, C2, ldc)
+            torch.cuda.synchronize()
+            extra["rocblas_dgemm_tflops"] = round(flops_per_step * reps / (time.perf_counter() - t1) / 1e12, 3)
+            extra["rocblas_dgemm_relative_residual"] = O.relative_residual_sampled(
+                opa, opb, M, N, K, a_h, b_h, C2.cpu().numpy().T, ns=2048)
+            extra["speedup_vs_rocblas_dgemm"] = round(value / world / extra["rocblas_dgemm_tflops"], 3)
+            out["extra"] = extra
+
+        if not args.no_cpu and world == 1:
+            from oracle import oracle as O
+            # bounded sample of the same workload: the top-left 1024x1024 block of C over the full K
+            ms_, ns_ = min(M, 1024), min(N, 1024)
+            a_h = A.cpu().numpy().T
+            b_h = B.cpu().numpy().T
+            a_s = np.asfortranarray(a_h[:ms_, :] if opa == "N" else a_h[:, :ms_])
+            b_s = np.asfortranarray(b_h[:, :ns_] if opb == "N" else b_h[:ns_, :])
+            c_s = np.zeros((ms_, ns_), order="F")
+            t1 = time.perf_counter()
+            O.gemm(opa, opb, ms_, ns_, K, 1.0, a_s, b_s, 0.0, c_s, S, O.ORDER_REFERENCE)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(2.0 * ms_ * ns_ * K / dt / 1e12, 5), "unit": "TFLOP/s",
+                "cores": O.max_threads(), "kind": "port",
+                "sample": f"oracle (plain C + OpenMP port of the reference algorithm, reference summation order) on the "
+                          f"{ms_}x{ns_} leading block of C, full K={K}, {args.mode}: {dt:.1f} s",
+            }
+            # north_star's CPU comparator: OpenBLAS DGEMM (numpy's bundled OpenBLAS), all host cores
+            nb = min(N, 4096)
+            x = np.asfortranarray(a_h[:nb, :nb])
+            y = np.asfortranarray(b_h[:nb, :nb])
+            x @ y
+            best = 1e30
+            for _ in range(3):
+                t1 = time.perf_counter()
+                x @ y
+                best = min(best, time.perf_counter() - t1)
+            out["cpu_baseline"]["openblas_dgemm"] = {
+                "value": round(2.0 * nb ** 3 / best / 1e12, 4), "unit": "TFLOP/s", "cores": os.cpu_count(),
+                "sample": f"numpy.matmul (bundled OpenBLAS) FP64 {nb}^3, best of 3"}
+
+        print(json.dumps(out), flush=True)
+
+    barrier()
+    oz.destroy(h)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:  # PyTorch bundles its own libamdhip64.so.7: load it FIRST so both share one HIP runtime
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise OzimmuLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m ozimmu_amd.build` (hipcc, gfx950). "

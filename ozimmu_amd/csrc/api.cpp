@@ -71,6 +71,7 @@ struct Workspace {
   double *ea, *eb;
   int8_t *planes_a, *planes_b;
   double *acc;
+  uint32_t *phase;
   size_t exps_bytes;
   size_t total;
 };
@@ -85,7 +86,8 @@ static Workspace carve(void *base, size_t m, size_t n, size_t k, int S, bool nee
   };
   w.exps_a = (uint32_t *)take(4 * m);
   w.exps_b = (uint32_t *)take(4 * n);
-  w.exps_bytes = off; // exps_a and exps_b are adjacent: one memset
+  w.phase = (uint32_t *)take(8 * 256); // one 256-byte line per XCD
+  w.exps_bytes = off; // exps_a, exps_b and phase are adjacent: one memset
   w.ea = (double *)take(8 * m);
   w.eb = (double *)take(8 * n);
   w.planes_a = (int8_t *)take(tiled_plane_bytes(m, k, S));
@@ -181,6 +183,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   g.c = c;
   g.ldc = ldc;
   g.acc = w.acc;
+  g.phase = env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) ? nullptr : w.phase;
   g.dump = dump;
   g.dump_only = dump ? 1 : 0;
   const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);

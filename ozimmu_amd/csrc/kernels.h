@@ -25,6 +25,7 @@ struct SliceGemmArgs {
   double *acc; // [N][M] FP64 partial sums (multi-pass only)
   int acc_in;  // start the fma chain from acc instead of 0
   int final;   // 1: scale + alpha/beta -> C; 0: -> acc
+  uint32_t *phase; // 8 advisory words (one per XCD): k-block the XCD's workgroups are at; zeroed per call
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue
 };

@@ -4,7 +4,7 @@
 //   for each pair (i,j), i+j <= S+1:  cublasGemmEx(INT8->INT32)  (/root/reference/src/gemm.cu:315-329)
 //                                     accumulate_in_f64            (src/gemm.cu:77-102, :394-401)
 //   axby                                                           (src/gemm.cu:124-158)
-// by ONE kernel per pass that keeps a 64x64 output tile resident in registers:
+// by ONE kernel per pass (slice_gemm_kernel.h) that keeps a 64x64 output tile resident in registers:
 //
 //  * every k-step (32 k-bytes) the workgroup stages ALL needed slices of its 64 A-rows and 64 B-rows
 //    HBM -> LDS with global_load_lds (1 KiB fragment blocks, layout.h), double buffered;
@@ -22,152 +22,27 @@
 // register the 32 lanes of a half-wave store 32 consecutive doubles of column-major C (256 B runs).
 //
 // Roofline: MFMA INT8 (dense 1024 MAC/clk/SIMD).  Algorithmic work per launch: P*2*M*N*K ops.
-#include <hip/hip_runtime.h>
-
-#include "kernels.h"
-#include "layout.h"
+#include "slice_gemm_kernel.h"
 
 namespace ozhip {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-#define OZ_AS1 __attribute__((address_space(1)))
-#define OZ_AS3 __attribute__((address_space(3)))
-
-// 2^e as a double, e in the normal range
-__device__ __forceinline__ double pow2d(int e) {
-  return __longlong_as_double((long long)(1023 + e) << 52);
-}
-
-template <int S, int D0, int ND>
-__global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs p) {
-  // slices 0..SL-1 of both operands are needed for diagonals d=i+j in [D0, D0+ND)
-  constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
-  constexpr int STAGE_BYTES = 4 * SL * FRAG_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-  // ---- workgroup -> output tile, XCD aware (guide §5.5 T1, bijective form) -------------------------
-  // hardware places workgroup b on XCD b%8: give each XCD a contiguous run of logical tile ids, and
-  // order the ids so that 64 consecutive ones (what one XCD runs concurrently: 32 CUs x 2) form an
-  // 8x8 patch of tiles sharing 512 A-rows and 512 B-rows in that XCD's L2.
-  const uint32_t nb = p.tiles_m * p.tiles_n;
-  uint32_t lid;
-  {
-    const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3, q = nb >> 3, r = nb & 7u;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  uint32_t tm, tn;
-  {
-    const uint32_t band_tiles = 8u * p.tiles_n, nbands = (p.tiles_m + 7u) >> 3;
-    uint32_t band = lid / band_tiles;
-    if (band > nbands - 1) band = nbands - 1;
-    const uint32_t rem = lid - band * band_tiles;
-    const uint32_t h = (p.tiles_m - band * 8u) < 8u ? (p.tiles_m - band * 8u) : 8u;
-    tn = rem / h;
-    tm = band * 8u + rem % h;
-  }
-
-  // ---- staging: wave w copies row-block w of {A0, A1, B0, B1}, SL fragment blocks per k-step -------
-  const int8_t *src = (wave < 2) ? p.a_planes + (size_t)(2 * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
-                                 : p.b_planes + (size_t)(2 * tn + (wave - 2)) * p.KB * (size_t)(S * FRAG_BYTES);
-  src += lane * 16;
-  auto stage = [&](int buf, uint32_t kb) {
-    const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
-    char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
-#pragma unroll
-    for (int s = 0; s < SL; s++)
-      __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(g + s * FRAG_BYTES),
-                                       (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, 0);
-  };
-
-  const int wm = wave & 1, wn = wave >> 1;
-  v16i acc[ND];
-#pragma unroll
-  for (int d = 0; d < ND; d++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[d][r] = 0;
-
-  int cur = 0;
-  if (p.kb0 < p.kb1) stage(0, p.kb0);
-  for (uint32_t kb = p.kb0; kb < p.kb1; kb++) {
-    __syncthreads(); // own glds landed (vmcnt(0) precedes the barrier) + everyone done with buf cur^1
-    if (kb + 1 < p.kb1) stage(cur ^ 1, kb + 1);
-    const char *la = smem + cur * STAGE_BYTES + wm * (SL * FRAG_BYTES) + lane * 16;
-    const char *lb = smem + cur * STAGE_BYTES + (2 + wn) * (SL * FRAG_BYTES) + lane * 16;
-    v4i bf[SL];
-#pragma unroll
-    for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb + j * FRAG_BYTES);
-#pragma unroll
-    for (int i = 0; i < SL; i++) {
-      const v4i af = *(const v4i *)(la + i * FRAG_BYTES);
-#pragma unroll
-      for (int j = 0; j < SL; j++) {
-        const int d = i + j;
-        if (d >= D0 && d < D0 + ND && d <= S - 1)
-          acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af, acc[d - D0], 0, 0, 0);
-      }
-    }
-    cur ^= 1;
-  }
-
-  // ---- epilogue ------------------------------------------------------------------------------------
-  const uint32_t m = tm * 64 + wm * 32 + (lane & 31);
-  const uint32_t nbase = tn * 64 + wn * 32 + 4 * (lane >> 5);
-  if (p.dump) { // test hook: raw INT32 diagonal sums, [ND][N][M]
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
-      if (m < p.M && n < p.N)
-#pragma unroll
-        for (int d = 0; d < ND; d++) p.dump[((size_t)d * p.N + n) * p.M + m] = acc[d][r];
-    }
-    if (p.dump_only) return;
-  }
-  double sc[ND];
-#pragma unroll
-  for (int d = 0; d < ND; d++) sc[d] = pow2d(46 - p.L * (D0 + d + 2));
-  const bool mok = m < p.M;
-  const double ea = mok ? p.ea[m] : 0.0;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
-    if (!mok || n >= p.N) continue;
-    double x = p.acc_in ? p.acc[(size_t)n * p.M + m] : 0.0;
-#pragma unroll
-    for (int d = 0; d < ND; d++) x = fma((double)acc[d][r], sc[d], x);
-    if (!p.final) {
-      p.acc[(size_t)n * p.M + m] = x;
-    } else {
-      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
-      const double v = x * 0x1p-44 * ea * p.eb[n];
-      double *cp = p.c + (size_t)n * p.ldc + m;
-      if (p.beta != 0.0)
-        *cp = fma(p.alpha, v, p.beta * *cp);
-      else
-        *cp = p.alpha * v;
-    }
-  }
-}
-
-// ---- host-side dispatch ----------------------------------------------------------------------------
 
 template <int S, int D0, int ND>
 static hipError_t launch_one(const SliceGemmArgs &a, hipStream_t stream) {
   constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
   constexpr size_t lds = 2 * 4 * SL * FRAG_BYTES;
+  // the prefetch-2 loop keeps all 2*SL fragments in registers next to the 16*ND accumulators: beyond
+  // ~232 of the 256 VGPRs (2 waves/SIMD) it would spill inside the k loop, so those passes (second pass
+  // of S >= 16) stream the A fragments instead (prefetch distance 1).
+  constexpr int VAR_PRODUCTION = (16 * ND + 8 * SL <= 232) ? VAR_SHIPPED : (VAR_SHIPPED & ~VAR_PF2);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)slice_gemm_kernel<S, D0, ND>,
+    hipError_t e = hipFuncSetAttribute((const void *)slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const uint32_t nb = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND>), dim3(nb), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION>), dim3(nb), dim3(256), lds, stream, a);
   return hipGetLastError();
 }
 

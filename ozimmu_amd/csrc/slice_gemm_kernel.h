@@ -1,0 +1,272 @@
+// slice_gemm_kernel.h — device code of the fused INT8 slice GEMM (see slice_gemm.hip for the design notes).
+// Kept in a header so that tools/gemm_ablate.hip can instantiate experimental variants (VAR != 0) of the
+// very same kernel for within-process A/B timing; the library only instantiates VAR = 0.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "layout.h"
+
+namespace ozhip {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define OZ_AS1 __attribute__((address_space(1)))
+#define OZ_AS3 __attribute__((address_space(3)))
+
+// VAR bits (experiments only): low 2 bits = ablation: 1 = no HBM->LDS staging and no barriers (LDS holds
+// garbage), 2 = MFMA only (no LDS reads either).
+constexpr int VAR_ABL_MASK = 7;
+constexpr int VAR_NO_GLOBAL = 1;
+constexpr int VAR_MFMA_ONLY = 2;
+constexpr int VAR_GLOBAL_NO_SYNC = 3; // staging issued but never waited for / no barrier (races; timing only)
+constexpr int VAR_SYNC_NO_GLOBAL = 4; // barrier every k-step but no staging
+constexpr int VAR_GLOBAL_TO_REG = 5;  // staging loads go to registers (no LDS-DMA write), never used
+constexpr int VAR_PF2 = 8;            // main loop with prefetch distance 2 (fragments in registers)
+constexpr int VAR_NO_CU_SWIZZLE = 16; // plain (p%8, p/8) tile order inside a patch
+constexpr int VAR_PH_EVERY = 32;      // publish the phase hint every k-step
+constexpr int VAR_PH_LEAD2 = 64;      // late joiners start 2 k-steps ahead of the published phase
+// what the library ships (tools/gemm_ablate.hip A/B, N=8192 S=9: 18.9 ms vs 20.0 ms for VAR=0)
+constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2;
+
+// 2^e as a double, e in the normal range
+__device__ __forceinline__ double pow2d(int e) {
+  return __longlong_as_double((long long)(1023 + e) << 52);
+}
+
+template <int S, int D0, int ND, int VAR = 0>
+__global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs p) {
+  // slices 0..SL-1 of both operands are needed for diagonals d=i+j in [D0, D0+ND)
+  constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
+  constexpr int STAGE_BYTES = 4 * SL * FRAG_BYTES;
+  constexpr int ABL = VAR & VAR_ABL_MASK;
+  constexpr uint32_t PH_MASK = (VAR & VAR_PH_EVERY) ? 0u : 7u; // publish the phase hint every (mask+1)-th k-step
+  constexpr uint32_t PH_LEAD = (VAR & VAR_PH_LEAD2) ? 2u : 0u; // joiners start this many k-steps ahead of the hint
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // ---- workgroup -> output tile, XCD aware (guide §5.5 T1, bijective form) -------------------------
+  // hardware places workgroup b on XCD b%8: give each XCD a contiguous run of logical tile ids, and
+  // order the ids so that 64 consecutive ones (what one XCD runs concurrently: 32 CUs x 2) form an
+  // 8x8 patch of tiles sharing 512 A-rows and 512 B-rows in that XCD's L2.
+  const uint32_t nb = p.tiles_m * p.tiles_n;
+  uint32_t lid;
+  {
+    const uint32_t bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3, q = nb >> 3, r = nb & 7u;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  uint32_t tm, tn;
+  {
+    const uint32_t band_tiles = 8u * p.tiles_n, nbands = (p.tiles_m + 7u) >> 3;
+    uint32_t band = lid / band_tiles;
+    if (band > nbands - 1) band = nbands - 1;
+    const uint32_t rem = lid - band * band_tiles;
+    const uint32_t h = (p.tiles_m - band * 8u) < 8u ? (p.tiles_m - band * 8u) : 8u;
+    tn = rem / h;
+    tm = band * 8u + rem % h;
+    if constexpr ((VAR & VAR_NO_CU_SWIZZLE) == 0) {
+      // Within a full 8x8 patch, permute the 64 tiles so that the two workgroups that share a CU never
+      // share an A or B row-block.  Measured placement (tools/probe_dispatch.hip): an XCD's 64 concurrent
+      // workgroups go one per CU first, so positions p and p+32 of the patch are co-resident; with the
+      // plain (tm,tn) = (p%8, p/8) order they load the SAME A chunks at the same time and the CU's L1
+      // (TCP) stalls on the pending lines (TCP_PENDING_STALL ~54 % of cycles).  (tm,tn) = (a+b, a+2b) mod 8
+      // for p = 8a+b is a bijection of the patch whose pairs at distance 1, 2, 8, 16, 32 differ in both.
+      const uint32_t patch = rem >> 6;
+      if (h == 8u && patch * 8u + 8u <= p.tiles_n) {
+        const uint32_t pp = rem & 63u, a = pp >> 3, b = pp & 7u;
+        tm = band * 8u + ((a + b) & 7u);
+        tn = patch * 8u + ((a + 2u * b) & 7u);
+      }
+    }
+  }
+
+  // ---- staging: wave w copies row-block w of {A0, A1, B0, B1}, SL fragment blocks per k-step -------
+  const int8_t *src = (wave < 2) ? p.a_planes + (size_t)(2 * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
+                                 : p.b_planes + (size_t)(2 * tn + (wave - 2)) * p.KB * (size_t)(S * FRAG_BYTES);
+  src += lane * 16;
+  v4i regstage[SL]; // VAR_GLOBAL_TO_REG only
+  auto stage = [&](int buf, uint32_t kb) {
+    if constexpr (ABL == VAR_GLOBAL_TO_REG) { // same HBM/L2 traffic, but no LDS write: isolates the LDS-DMA cost
+      const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
+#pragma unroll
+      for (int s = 0; s < SL; s++) asm volatile("" ::"v"(regstage[s])); // previous data must have landed
+#pragma unroll
+      for (int s = 0; s < SL; s++) regstage[s] = *(const v4i *)(g + s * FRAG_BYTES);
+      return;
+    }
+    if constexpr (ABL != 0 && ABL != VAR_GLOBAL_NO_SYNC) return;
+    const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
+    char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
+#pragma unroll
+    for (int s = 0; s < SL; s++)
+      __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(g + s * FRAG_BYTES),
+                                       (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, 0);
+  };
+
+  const int wm = wave & 1, wn = wave >> 1;
+  v16i acc[ND];
+#pragma unroll
+  for (int d = 0; d < ND; d++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[d][r] = 0;
+
+  // ---- circular K with a per-XCD phase hint ------------------------------------------------------------
+  // Integer accumulation is exact, so a workgroup may sweep its k-blocks in any rotation.  Workgroups of
+  // one XCD share A/B panels through that XCD's L2 only while they are at (nearly) the same k; a
+  // workgroup that starts late therefore begins at the k-block its neighbours are currently at (a racy,
+  // advisory word per XCD) and wraps around.  Performance only: any value gives the same result.
+  const uint32_t nk = p.kb1 - p.kb0;
+  // one 256-byte line per XCD; published with a PLAIN store (stays in that XCD's L2, no fabric write)
+  // every 8th k-step: a same-address write-through from 512 workgroups per k-step saturates the memory
+  // side (measured 8x slowdown).
+  uint32_t *phase = p.phase ? p.phase + 64u * (blockIdx.x & 7u) : nullptr;
+  uint32_t koff = 0;
+  if (phase && nk > 1) {
+    if (threadIdx.x == 0)
+      *(volatile uint32_t *)smem = __hip_atomic_load(phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    koff = (*(volatile uint32_t *)smem + PH_LEAD) % nk;
+    __syncthreads();
+  }
+  koff = __builtin_amdgcn_readfirstlane(koff);
+
+  v4i cf[2]; // MFMA-only ablation operands
+  if constexpr (ABL == VAR_MFMA_ONLY) {
+    cf[0] = v4i{lane, lane * 3, 7, 1};
+    cf[1] = v4i{lane * 5, 1, lane, 9};
+    asm volatile("" : "+v"(cf[0]), "+v"(cf[1]));
+  }
+
+  int cur = 0;
+  if constexpr ((VAR & VAR_PF2) != 0) {
+    // ---- prefetch distance 2 on two LDS buffers ------------------------------------------------------
+    // The HBM/L2 -> LDS stream is latency bound (Little: bytes in flight / latency): with one stage in
+    // flight per workgroup (72 KiB per CU) a k-step must land within one iteration (~1.7 us), which the
+    // loaded L2-miss latency exceeds.  Here every wave copies its 2*SL fragments to registers right after
+    // the stage lands, the buffer is released by a second barrier and immediately refilled with the
+    // stage two k-steps ahead: each stage gets ~2 iterations to land, 144 KiB in flight per CU.
+    // Waits are counted (vmcnt(SL) = "the older of my two stages has landed"), barriers are raw
+    // s_barrier: __syncthreads() would drain vmcnt(0) (guide §5 "Pipelining across barriers").
+    auto koff_next = [&](uint32_t k) { return k + 1 == nk ? 0u : k + 1; };
+    uint32_t k_issue = koff;
+    if (nk) stage(0, p.kb0 + k_issue);
+    k_issue = koff_next(k_issue);
+    if (nk > 1) stage(1, p.kb0 + k_issue);
+    k_issue = koff_next(k_issue);
+    const char *la0 = smem + wm * (SL * FRAG_BYTES) + lane * 16;
+    const char *lb0 = smem + (2 + wn) * (SL * FRAG_BYTES) + lane * 16;
+    for (uint32_t it = 0; it < nk; it++) {
+      if (it + 1 < nk)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); // stage `it` is in LDS for every wave
+      asm volatile("" ::: "memory");
+      v4i bf[SL], af[SL];
+#pragma unroll
+      for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb0 + cur * STAGE_BYTES + j * FRAG_BYTES);
+#pragma unroll
+      for (int i = 0; i < SL; i++) af[i] = *(const v4i *)(la0 + cur * STAGE_BYTES + i * FRAG_BYTES);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); // every wave holds its fragments: buffer `cur` is free
+      asm volatile("" ::: "memory");
+      if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
+        __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      koff = koff_next(koff);
+      if (it + 2 < nk) {
+        stage(cur, p.kb0 + k_issue);
+        k_issue = koff_next(k_issue);
+      }
+#pragma unroll
+      for (int i = 0; i < SL; i++)
+#pragma unroll
+        for (int j = 0; j < SL; j++) {
+          const int d = i + j;
+          if (d >= D0 && d < D0 + ND && d <= S - 1)
+            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[d - D0], 0, 0, 0);
+        }
+      cur ^= 1;
+    }
+  } else {
+  if (nk) stage(0, p.kb0 + koff);
+  for (uint32_t it = 0; it < nk; it++) {
+    if constexpr (ABL == 0 || ABL == VAR_SYNC_NO_GLOBAL) {
+      __syncthreads(); // own glds landed (vmcnt(0) precedes the barrier) + everyone done with buf cur^1
+      if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
+        __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    koff = koff + 1 == nk ? 0 : koff + 1;
+    if (it + 1 < nk) stage(cur ^ 1, p.kb0 + koff);
+    const char *la = smem + cur * STAGE_BYTES + wm * (SL * FRAG_BYTES) + lane * 16;
+    const char *lb = smem + cur * STAGE_BYTES + (2 + wn) * (SL * FRAG_BYTES) + lane * 16;
+    if constexpr (ABL == VAR_MFMA_ONLY) {
+#pragma unroll
+      for (int i = 0; i < SL; i++)
+#pragma unroll
+        for (int j = 0; j < SL; j++) {
+          const int d = i + j;
+          if (d >= D0 && d < D0 + ND && d <= S - 1)
+            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf[j & 1], cf[i & 1], acc[d - D0], 0, 0, 0);
+        }
+    } else {
+      v4i bf[SL];
+#pragma unroll
+      for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb + j * FRAG_BYTES);
+#pragma unroll
+      for (int i = 0; i < SL; i++) {
+        const v4i af = *(const v4i *)(la + i * FRAG_BYTES);
+#pragma unroll
+        for (int j = 0; j < SL; j++) {
+          const int d = i + j;
+          if (d >= D0 && d < D0 + ND && d <= S - 1)
+            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af, acc[d - D0], 0, 0, 0);
+        }
+      }
+    }
+    cur ^= 1;
+  }
+  } // !VAR_PF2
+
+  // ---- epilogue ------------------------------------------------------------------------------------
+  const uint32_t m = tm * 64 + wm * 32 + (lane & 31);
+  const uint32_t nbase = tn * 64 + wn * 32 + 4 * (lane >> 5);
+  if (p.dump) { // test hook: raw INT32 diagonal sums, [ND][N][M]
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
+      if (m < p.M && n < p.N)
+#pragma unroll
+        for (int d = 0; d < ND; d++) p.dump[((size_t)d * p.N + n) * p.M + m] = acc[d][r];
+    }
+    if (p.dump_only) return;
+  }
+  double sc[ND];
+#pragma unroll
+  for (int d = 0; d < ND; d++) sc[d] = pow2d(46 - p.L * (D0 + d + 2));
+  const bool mok = m < p.M;
+  const double ea = mok ? p.ea[m] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
+    if (!mok || n >= p.N) continue;
+    double x = p.acc_in ? p.acc[(size_t)n * p.M + m] : 0.0;
+#pragma unroll
+    for (int d = 0; d < ND; d++) x = fma((double)acc[d][r], sc[d], x);
+    if (!p.final) {
+      p.acc[(size_t)n * p.M + m] = x;
+    } else {
+      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
+      const double v = x * 0x1p-44 * ea * p.eb[n];
+      double *cp = p.c + (size_t)n * p.ldc + m;
+      if (p.beta != 0.0)
+        *cp = fma(p.alpha, v, p.beta * *cp);
+      else
+        *cp = p.alpha * v;
+    }
+  }
+}
+
+} // namespace ozhip
