@@ -45,6 +45,40 @@ def parse():
     return p.parse_args()
 
 
+def timed_region(step, steps, warmup, world, sync, device):
+    """The timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier + device
+    synchronisation on both sides; returns the MAX over ranks of the elapsed seconds.  `sync` is
+    torch.cuda.synchronize on a GPU (a no-op in the CPU/gloo test of this function)."""
+    import torch
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job_value(flops_per_step, steps, world, elapsed):
+    """replicas only (weak scaling): every rank did `steps` whole DGEMMs; aggregate = world * per-rank work"""
+    return world * flops_per_step * steps / elapsed / 1e12
+
+
 def main():
     args = parse()
     import numpy as np
@@ -95,24 +129,10 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_region(step, args.steps, args.warmup, world, torch.cuda.synchronize, "cuda")
 
     flops_per_step = 2.0 * M * N * K
-    value = world * flops_per_step * args.steps / elapsed / 1e12
+    value = whole_job_value(flops_per_step, args.steps, world, elapsed)
     out = {
         "metric": "DGEMM-equivalent TFLOP/s (2*M*N*K/t), Ozaki-scheme INT8 DGEMM",
         "value": round(value, 3),

@@ -166,7 +166,8 @@ rocblas_status rocblas_create_handle(rocblas_handle *handle) {
   if (st == rocblas_status_success && t_depth == 0) {
     g_live_vendor_handles++;
     // the reference pre-sizes the workspace for a 1024^3 fp64_int8_9 GEMM here (src/cublas.cu:12-16, :109-110)
-    if (get_compute_mode() != OZIMMU_DGEMM)
+    const ozimmu_compute_mode_t mode = get_compute_mode();
+    if (is_int8_mode(mode) || mode == OZIMMU_FP64_INT8_AUTO)
       if (ozimmu_hip_handle_t h = get_global_handle())
         ozimmu_hip_reallocate_working_memory(
             h, ozimmu_hip_working_memory_size(OZIMMU_OP_N, OZIMMU_OP_N, 1024, 1024, 1024, OZIMMU_REAL,

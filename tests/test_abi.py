@@ -1,0 +1,127 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol that
+include/ozimmu_hip.h declares plus the interposed rocBLAS/hipBLAS entry points, and its host-only logic
+(mode names, slice width, workspace sizing) follows the reference.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import ozimmu_amd
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ozimmu_hip.h")
+
+INTERPOSED = ["rocblas_create_handle", "rocblas_destroy_handle", "rocblas_dgemm", "rocblas_dgemm_64",
+              "rocblas_gemm_ex", "rocblas_dgemm_strided_batched", "hipblasDgemm", "hipblasGemmEx"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ozimmu_amd import build
+    build.build()
+    return ozimmu_amd.lib()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ozimmu_hip_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_api():
+    names = declared_functions()
+    # include/ozimmu/ozimmu.hpp:47-100, flattened to C
+    for f in ["create", "destroy", "set_stream", "enable_profiling", "disable_profiling", "print_profiler_result",
+              "clear_profiler_result", "set_auto_mantissa_loss_threashold", "get_auto_mantissa_loss_threashold",
+              "reallocate_working_memory", "gemm", "auto_mode_select", "get_compute_mode_name_str",
+              "get_bits_per_int8"]:
+        assert "ozimmu_hip_" + f in names, f
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_functions() + INTERPOSED:
+        assert hasattr(lib, name), f"{name} is declared in include/ozimmu_hip.h but not exported"
+
+
+def test_exports_are_unmangled_c_symbols():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", ozimmu_amd.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    for name in declared_functions() + INTERPOSED:
+        assert name in exported
+
+
+def test_no_link_time_dependency_on_vendor_blas():
+    """originals are resolved with dlsym(RTLD_NEXT) at run time (src/utils.hpp:117-141), never linked"""
+    out = subprocess.check_output(["readelf", "-d", ozimmu_amd.LIB_PATH], text=True)
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert not any("rocblas" in n or "hipblas" in n for n in needed), needed
+    assert any("amdhip64" in n for n in needed)
+
+
+def test_compute_mode_enum_and_names(lib):
+    # enum order of include/ozimmu/ozimmu.hpp:14-37
+    expect = ["sgemm", "dgemm"] + [f"fp64_int8_{s}" for s in range(3, 19)] + ["fp64_int8_auto"]
+    for i, name in enumerate(expect):
+        assert ozimmu_amd.get_compute_mode_name_str(i) == name
+        assert lib.ozimmu_hip_compute_mode_from_str(name.encode()) == i
+        assert O.num_split_from_mode(name) == {"sgemm": -2, "dgemm": -1, "fp64_int8_auto": 0}.get(
+            name, ozimmu_amd.get_num_split(i))
+    assert lib.ozimmu_hip_get_compute_mode_name_str(19) is None
+    # src/cublas.cu:18-48: unknown / unset -> dgemm
+    for bad in [b"", b"fp64_int8_2", b"fp64_int8_19", b"FP64_INT8_9", b"auto"]:
+        assert lib.ozimmu_hip_compute_mode_from_str(bad) == ozimmu_amd.dgemm
+    assert lib.ozimmu_hip_compute_mode_from_str(None) == ozimmu_amd.dgemm
+    assert ozimmu_amd.fp64_int8_9 == 8 and ozimmu_amd.fp64_int8_auto == 18
+
+
+def test_bits_per_int8_matches_oracle(lib):
+    for k in list(range(0, 70)) + [1000, 1 << 17, (1 << 17) + 1, 1 << 19, (1 << 19) + 1, 1 << 21, 1 << 23,
+                                   (1 << 23) + 5, 1 << 25, 1 << 27, 1 << 29, (1 << 30)]:
+        assert ozimmu_amd.get_bits_per_int8(k) == O.bits_per_int8(k), k
+
+
+def test_working_memory_size(lib):
+    # grows with S, m, n, k; zero for non-Ozaki modes (the workspace is library-owned: src/handle.cu:95-144)
+    f = lib.ozimmu_hip_working_memory_size
+    base = f(0, 0, 1024, 1024, 1024, ozimmu_amd.real, ozimmu_amd.fp64_int8_9)
+    assert base >= 2 * 9 * 1024 * 1024            # at least the slice planes
+    assert base < 2 * 9 * 1024 * 1024 * 1.2 + (1 << 20)
+    assert f(0, 0, 1024, 1024, 1024, ozimmu_amd.real, ozimmu_amd.fp64_int8_12) > base   # + FP64 partials
+    assert f(0, 0, 2048, 1024, 1024, ozimmu_amd.real, ozimmu_amd.fp64_int8_9) > base
+    assert f(0, 0, 1024, 1024, 1024, ozimmu_amd.real, ozimmu_amd.dgemm) == 0
+    assert f(0, 0, 1024, 1024, 1024, ozimmu_amd.complx, ozimmu_amd.fp64_int8_9) == 0
+    assert f(0, 0, 1024, 1024, 1024, ozimmu_amd.real, ozimmu_amd.fp64_int8_auto) >= \
+        f(0, 0, 1024, 1024, 1024, ozimmu_amd.real, ozimmu_amd.fp64_int8_18)
+
+
+def test_null_handle_is_rejected_not_dereferenced(lib):
+    """the reference dereferences its global handle unchecked (src/cublas.cu:144); the C ABI must not"""
+    al = ctypes.c_double(1.0)
+    assert lib.ozimmu_hip_gemm(None, 0, 0, 4, 4, 4, ctypes.addressof(al), None, 4, None, 4, ctypes.addressof(al),
+                               None, 4, ozimmu_amd.fp64_int8_6, ozimmu_amd.real) == 1
+    assert lib.ozimmu_hip_destroy(None) == 0
+    assert lib.ozimmu_hip_reallocate_working_memory(None, 1 << 20) == 0
+    lib.ozimmu_hip_set_stream(None, None)
+
+
+def test_product_has_no_cpu_fallback():
+    """the package never imports the oracle; a missing library is a loud error"""
+    src = open(os.path.join(ROOT, "ozimmu_amd", "__init__.py")).read()
+    for f in os.listdir(os.path.join(ROOT, "ozimmu_amd", "csrc")):
+        text = open(os.path.join(ROOT, "ozimmu_amd", "csrc", f)).read()
+        assert "ozaki_oracle" not in text and "liboz_oracle" not in text, f
+    assert "liboz_oracle" not in src and "import oracle" not in src and "from oracle" not in src
+    import importlib
+    saved = ozimmu_amd.LIB_PATH
+    try:
+        ozimmu_amd._lib = None
+        ozimmu_amd.LIB_PATH = saved + ".does-not-exist"
+        with pytest.raises(ozimmu_amd.OzimmuLibraryMissing):
+            ozimmu_amd.lib()
+    finally:
+        ozimmu_amd.LIB_PATH = saved
+        ozimmu_amd._lib = None
+        importlib.reload(ozimmu_amd)

@@ -1,0 +1,168 @@
+"""GPU tests of the LD_PRELOAD boundary with the REAL rocBLAS / hipBLAS underneath (reference:
+src/cublas.cu:103-513; the reference's own tests never exercise its interposer)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+import ozimmu_amd
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DRIVER = r"""
+#include <hip/hip_runtime_api.h>
+#include <rocblas/rocblas.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+// C = alpha*op(A)*op(B) + beta*C through rocblas_dgemm / rocblas_gemm_ex / strided batched, checked against a
+// long double host reference on sampled entries; prints "RESIDUAL <which> <value>".
+static double residual(const std::vector<double>& A, const std::vector<double>& B, const std::vector<double>& C0,
+                       const std::vector<double>& C, int m, int n, int k, double alpha, double beta, bool ta, bool tb) {
+  long double num = 0, den = 0;
+  unsigned s = 12345;
+  for (int t = 0; t < 600; t++) {
+    s = s * 1664525u + 1013904223u; int i = (s >> 8) % m;
+    s = s * 1664525u + 1013904223u; int j = (s >> 8) % n;
+    long double acc = 0;
+    for (int kk = 0; kk < k; kk++) {
+      const double a = ta ? A[(size_t)i * k + kk] : A[(size_t)kk * m + i];
+      const double b = tb ? B[(size_t)kk * n + j] : B[(size_t)j * k + kk];
+      acc += (long double)a * b;
+    }
+    const long double truth = alpha * acc + beta * C0[(size_t)j * m + i];
+    const long double d = C[(size_t)j * m + i] - truth;
+    num += d * d; den += truth * truth;
+  }
+  return (double)sqrtl(num / den);
+}
+int main(int argc, char** argv) {
+  const int m = argc > 1 ? atoi(argv[1]) : 512, n = m + 64, k = m + 32;
+  const bool ta = argc > 2 && atoi(argv[2]), tb = argc > 3 && atoi(argv[3]);
+  const double alpha = 1.25, beta = -0.5;
+  std::vector<double> A((size_t)m * k), B((size_t)k * n), C0((size_t)m * n), C((size_t)m * n);
+  unsigned s = 1;
+  auto rnd = [&]() { s = s * 1103515245u + 12345u; return ((s >> 8) & 0xffffff) / 8388608.0 - 1.0; };
+  for (auto& x : A) x = rnd();
+  for (auto& x : B) x = rnd();
+  for (auto& x : C0) x = rnd();
+  double *dA, *dB, *dC;
+  hipMalloc(&dA, A.size() * 8); hipMalloc(&dB, B.size() * 8); hipMalloc(&dC, 3 * C.size() * 8);
+  hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice);
+  rocblas_handle h;
+  if (rocblas_create_handle(&h) != rocblas_status_success) return 2;
+  hipStream_t st; hipStreamCreate(&st); rocblas_set_stream(h, st);
+  const rocblas_operation oa = ta ? rocblas_operation_transpose : rocblas_operation_none;
+  const rocblas_operation ob = tb ? rocblas_operation_transpose : rocblas_operation_none;
+  const int lda = ta ? k : m, ldb = tb ? n : k;
+  // 1. rocblas_dgemm
+  hipMemcpy(dC, C0.data(), C.size() * 8, hipMemcpyHostToDevice);
+  if (rocblas_dgemm(h, oa, ob, m, n, k, &alpha, dA, lda, dB, ldb, &beta, dC, m) != rocblas_status_success) return 3;
+  hipStreamSynchronize(st);
+  hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
+  printf("RESIDUAL dgemm %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  // 2. rocblas_gemm_ex, all f64, in place
+  hipMemcpy(dC, C0.data(), C.size() * 8, hipMemcpyHostToDevice);
+  if (rocblas_gemm_ex(h, oa, ob, m, n, k, &alpha, dA, rocblas_datatype_f64_r, lda, dB, rocblas_datatype_f64_r, ldb, &beta,
+                      dC, rocblas_datatype_f64_r, m, dC, rocblas_datatype_f64_r, m, rocblas_datatype_f64_r,
+                      rocblas_gemm_algo_standard, 0, 0) != rocblas_status_success) return 4;
+  hipStreamSynchronize(st);
+  hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
+  printf("RESIDUAL gemm_ex %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  // 3. strided batched: 3 x the same product into 3 C's
+  for (int b = 0; b < 3; b++) hipMemcpy(dC + (size_t)b * m * n, C0.data(), C.size() * 8, hipMemcpyHostToDevice);
+  if (rocblas_dgemm_strided_batched(h, oa, ob, m, n, k, &alpha, dA, lda, 0, dB, ldb, 0, &beta, dC, m, (rocblas_stride)m * n, 3)
+      != rocblas_status_success) return 5;
+  hipStreamSynchronize(st);
+  hipMemcpy(C.data(), dC + (size_t)2 * m * n, C.size() * 8, hipMemcpyDeviceToHost);
+  printf("RESIDUAL strided_batched %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  rocblas_destroy_handle(h);
+  return 0;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gpu_interpose")
+    src = d / "driver.cpp"
+    src.write_text(DRIVER)
+    exe = d / "driver"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(src), "-o",
+                           str(exe), "-L/opt/rocm/lib", "-lrocblas", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def run(exe, args, **env):
+    e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
+    e.update({k: str(v) for k, v in env.items()})
+    p = subprocess.run([str(exe)] + [str(a) for a in args], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    res = {l.split()[1]: float(l.split()[2]) for l in p.stdout.splitlines() if l.startswith("RESIDUAL")}
+    return res, p.stdout
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_preloaded_rocblas_dgemm_runs_the_ozaki_path(driver, ta, tb):
+    thr = dict(OZIMMU_INTERCEPT_THRESHOLD_M=256, OZIMMU_INTERCEPT_THRESHOLD_N=256, OZIMMU_INTERCEPT_THRESHOLD_K=256)
+    native, _ = run(driver, [512, ta, tb])
+    assert all(v < 1e-14 for v in native.values())
+    oz, out = run(driver, [512, ta, tb], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_9",
+                  OZIMMU_INFO=1, OZIMMU_ENABLE_CULIP_PROFILING=1, **thr)
+    assert set(oz) == {"dgemm", "gemm_ex", "strided_batched"}
+    assert all(v < 1e-15 for v in oz.values()), oz           # the reference's gate, through the preload
+    assert "[ozIMMU LOG] Reallocated memory" in out           # src/handle.cu:69
+    # CULiP line format of src/cublas.cu:157-162 / src/culip.cu:19-39
+    ops = ("T" if ta else "N") + ("T" if tb else "N")
+    assert f"[CULiP Result][Dfp64_int8_9-{ops}-m512-n576-k544]" in out
+    # fewer slices -> visibly larger error: proves the environment knob reaches the kernel
+    coarse, _ = run(driver, [512, ta, tb], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_4", **thr)
+    assert all(1e-10 < v < 1e-6 for v in coarse.values()), coarse
+
+
+def test_thresholds_and_mode_gate_the_intercept(driver):
+    # default thresholds (1024) -> 512^3 passes through even with a mode set: no ozIMMU workspace traffic in the log
+    _, out = run(driver, [512, 0, 0], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_4", OZIMMU_INFO=1)
+    res, _ = run(driver, [512, 0, 0], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_4")
+    assert all(v < 1e-14 for v in res.values())               # native accuracy, not the 4-slice error
+    res, _ = run(driver, [512, 0, 0], LD_PRELOAD=ozimmu_amd.LIB_PATH)
+    assert all(v < 1e-14 for v in res.values())
+
+
+def test_auto_mode_through_the_preload(driver):
+    thr = dict(OZIMMU_INTERCEPT_THRESHOLD_M=256, OZIMMU_INTERCEPT_THRESHOLD_N=256, OZIMMU_INTERCEPT_THRESHOLD_K=256)
+    res, out = run(driver, [512, 0, 0], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_auto",
+                   OZIMMU_AUTO_AVG_MANTISSA_LOSS_THRESHOLD=1.5, OZIMMU_INFO=1, **thr)
+    assert "AUTO selected mode = fp64_int8_8, threshold average mantissa loss = 1.5" in out   # src/gemm.cu:632-635
+    assert all(v < 1e-15 for v in res.values())
+
+
+def test_pytorch_float64_matmul_is_intercepted():
+    """torch.mm(float64) -> hipblasDgemm -> rocblas_dgemm (undefined dynamic symbol in libhipblas) -> the shim"""
+    code = textwrap.dedent("""
+        import torch
+        torch.manual_seed(0)
+        a = torch.rand(1536, 1024, dtype=torch.float64, device="cuda") * 2 - 1
+        b = torch.rand(1024, 1280, dtype=torch.float64, device="cuda") * 2 - 1
+        c = a @ b
+        torch.cuda.synchronize()
+        ref = (a.cpu().to(torch.float64) @ b.cpu().to(torch.float64))
+        print("MAXDIFF %.3e" % (c.cpu() - ref).abs().max().item())
+    """)
+    e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
+    e.update(LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_3", OZIMMU_INFO="1")
+    p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr
+    diff3 = float([l for l in p.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()[1])
+    e["OZIMMU_COMPUTE_MODE"] = "fp64_int8_10"
+    p10 = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p10.returncode == 0, p10.stdout + p10.stderr
+    diff10 = float([l for l in p10.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()[1])
+    assert "[ozIMMU LOG]" in p.stdout
+    assert diff3 > 1e-6 and diff10 < 1e-11, (diff3, diff10)    # 3 slices are visibly coarse, 10 are FP64-accurate

@@ -236,3 +236,62 @@ def test_auto_mode_counters_and_selection(oz, fill, thr, op_a, op_b):
     mode = m_.auto_mode_select(h, op_a, op_b, m, n, k, a.dev, a.ld, b.dev, b.ld, m_.real, thr)
     expect = m_.dgemm if s_ref == 0 else m_.fp64_int8_3 + (s_ref - 3)
     assert mode == expect
+
+
+# ---------------------------------------------------------------- committed golden fixtures (tests/golden)
+
+import glob  # noqa: E402
+import os  # noqa: E402
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _dev_colmajor(arr):
+    """device copy of a column-major (Fortran) 2-D array; returns (tensor, ld)"""
+    import torch
+    assert arr.flags.f_contiguous
+    return torch.from_numpy(np.ascontiguousarray(arr.T)).cuda(), arr.shape[0]
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_hip_path_reproduces_golden(oz, path):
+    import torch
+    m_, h = oz
+    g = np.load(path)
+    op_a, op_b = str(g["op_a"]), str(g["op_b"])
+    m, n, k, S, L = (int(g[x]) for x in ("m", "n", "k", "S", "L"))
+    a, lda = _dev_colmajor(np.asfortranarray(g["a"]))
+    b, ldb = _dev_colmajor(np.asfortranarray(g["b"]))
+    ldo = g["planes_a"].shape[2]
+    # slices + max_exp
+    for which, rows, ref_p, ref_e, (mm, nn), src, ld, op, mat in (
+            ("A", m, g["planes_a"], g["max_exp_a"], (m, k), a, lda, op_a, m_.matrix_A),
+            ("B", n, g["planes_b"], g["max_exp_b"], (k, n), b, ldb, op_b, m_.matrix_B)):
+        out = torch.zeros((S, rows, ldo), dtype=torch.int8, device="cuda")
+        mx = torch.zeros((rows,), dtype=torch.float64, device="cuda")
+        assert m_.split_int8(h, out, ldo, mx, mm, nn, src, ld, op, mat, S, L) == 0
+        _sync()
+        np.testing.assert_array_equal(out.cpu().numpy(), ref_p)
+        np.testing.assert_array_equal(mx.cpu().numpy().view(np.uint64), ref_e.view(np.uint64))
+    # INT32 diagonal sums
+    d = torch.zeros((S, n, m), dtype=torch.int32, device="cuda")
+    assert m_.diagonal_sums(h, op_a, op_b, m, n, k, a, lda, b, ldb, S, d) == 0
+    _sync()
+    np.testing.assert_array_equal(d.cpu().numpy().transpose(0, 2, 1).astype(np.int64), g["diag"])
+    # FP64 result, bit-exact in the kernel's grouping; a few ulp of the partial-sum scale from the reference's
+    c, ldc = _dev_colmajor(np.asfortranarray(g["c0"]))
+    assert m_.gemm(h, op_a, op_b, m, n, k, float(g["alpha"]), a, lda, b, ldb, float(g["beta"]), c, ldc,
+                   f"fp64_int8_{S}") == 0
+    _sync()
+    got = c.cpu().numpy().T
+    np.testing.assert_array_equal(got.view(np.uint64), np.ascontiguousarray(g["c_diagonal_order"]).view(np.uint64))
+    fin = np.isfinite(g["c_reference_order"])
+    scale = np.abs(g["c_reference_order"][fin]).max()
+    assert np.abs(got[fin] - g["c_reference_order"][fin]).max() <= 16 * 2.0 ** -52 * scale
+    assert (np.isnan(got) == np.isnan(g["c_reference_order"])).all()
+    # auto mode
+    cnt = m_.mantissa_loss(h, op_a, op_b, m, n, k, a, lda, b, ldb)
+    assert cnt == g["auto_counters"].tolist()
+    sel = int(g["auto_selected"])
+    mode = m_.auto_mode_select(h, op_a, op_b, m, n, k, a, lda, b, ldb, m_.real, 1.5)
+    assert mode == (m_.dgemm if sel == 0 else m_.fp64_int8_3 + sel - 3)
