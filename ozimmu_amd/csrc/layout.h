@@ -16,7 +16,7 @@
 // linear LDS image (what global_load_lds requires), (b) the MFMA operand read is ds_read_b128 at
 // base + lane*16: contiguous, bank-conflict free, and (c) all S slices of a (row-block, k-block) are
 // adjacent, so a GEMM workgroup streams S KiB contiguous runs that advance linearly with k.
-// Rows are padded to a multiple of 64 and k to a multiple of 32 with zero slices.
+// Rows are padded to a multiple of 128 and k to a multiple of 32 with zero slices.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -26,7 +26,7 @@ namespace ozhip {
 constexpr int FRAG_ROWS = 32;    // rows per fragment block
 constexpr int FRAG_K = 32;       // k-bytes per fragment block
 constexpr int FRAG_BYTES = 1024; // FRAG_ROWS * FRAG_K
-constexpr int TILE_ROWS = 64;    // GEMM workgroup tile edge: row padding granularity
+constexpr int TILE_ROWS = 128;   // largest GEMM workgroup tile edge: row padding granularity
 
 inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 inline size_t row_blocks_padded(size_t rows) { return round_up(rows, TILE_ROWS) / FRAG_ROWS; }

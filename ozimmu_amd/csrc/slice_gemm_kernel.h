@@ -35,11 +35,14 @@ __device__ __forceinline__ double pow2d(int e) {
   return __longlong_as_double((long long)(1023 + e) << 52);
 }
 
-template <int S, int D0, int ND, int VAR = 0>
-__global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs p) {
+// WM = A row-blocks (of 32 rows) per workgroup: 2 -> 4 waves, 64x64 tile, two workgroups per CU;
+//                                            4 -> 8 waves, 128x64 tile, one workgroup per CU (-25 % staged bytes per MFMA)
+template <int S, int D0, int ND, int VAR = 0, int WM = 2>
+__global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemmArgs p) {
   // slices 0..SL-1 of both operands are needed for diagonals d=i+j in [D0, D0+ND)
   constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
-  constexpr int STAGE_BYTES = 4 * SL * FRAG_BYTES;
+  constexpr int STAGE_BYTES = (WM + 2) * SL * FRAG_BYTES;
+  constexpr uint32_t PH = 16 / WM; // tiles per patch along M: a patch is 512 rows x 512 columns
   constexpr int ABL = VAR & VAR_ABL_MASK;
   constexpr uint32_t PH_MASK = (VAR & VAR_PH_EVERY) ? 0u : 7u; // publish the phase hint every (mask+1)-th k-step
   constexpr uint32_t PH_LEAD = (VAR & VAR_PH_LEAD2) ? 2u : 0u; // joiners start this many k-steps ahead of the hint
@@ -60,14 +63,14 @@ __global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs 
   }
   uint32_t tm, tn;
   {
-    const uint32_t band_tiles = 8u * p.tiles_n, nbands = (p.tiles_m + 7u) >> 3;
+    const uint32_t band_tiles = PH * p.tiles_n, nbands = (p.tiles_m + PH - 1u) / PH;
     uint32_t band = lid / band_tiles;
     if (band > nbands - 1) band = nbands - 1;
     const uint32_t rem = lid - band * band_tiles;
-    const uint32_t h = (p.tiles_m - band * 8u) < 8u ? (p.tiles_m - band * 8u) : 8u;
+    const uint32_t h = (p.tiles_m - band * PH) < PH ? (p.tiles_m - band * PH) : PH;
     tn = rem / h;
-    tm = band * 8u + rem % h;
-    if constexpr ((VAR & VAR_NO_CU_SWIZZLE) == 0) {
+    tm = band * PH + rem % h;
+    if constexpr ((VAR & VAR_NO_CU_SWIZZLE) == 0 && WM == 2) {
       // Within a full 8x8 patch, permute the 64 tiles so that the two workgroups that share a CU never
       // share an A or B row-block.  Measured placement (tools/probe_dispatch.hip): an XCD's 64 concurrent
       // workgroups go one per CU first, so positions p and p+32 of the patch are co-resident; with the
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs 
   }
 
   // ---- staging: wave w copies row-block w of {A0, A1, B0, B1}, SL fragment blocks per k-step -------
-  const int8_t *src = (wave < 2) ? p.a_planes + (size_t)(2 * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
-                                 : p.b_planes + (size_t)(2 * tn + (wave - 2)) * p.KB * (size_t)(S * FRAG_BYTES);
+  const int8_t *src = (wave < WM) ? p.a_planes + (size_t)(WM * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
+                                  : p.b_planes + (size_t)(2 * tn + (wave - WM)) * p.KB * (size_t)(S * FRAG_BYTES);
+  const bool stager = wave < WM + 2; // WM = 4: waves 6,7 stage nothing
   src += lane * 16;
   v4i regstage[SL]; // VAR_GLOBAL_TO_REG only
   auto stage = [&](int buf, uint32_t kb) {
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs 
       return;
     }
     if constexpr (ABL != 0 && ABL != VAR_GLOBAL_NO_SYNC) return;
+    if (!stager) return;
     const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
     char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
 #pragma unroll
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs 
                                        (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, 0);
   };
 
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   v16i acc[ND];
 #pragma unroll
   for (int d = 0; d < ND; d++)
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs 
     if (nk > 1) stage(1, p.kb0 + k_issue);
     k_issue = koff_next(k_issue);
     const char *la0 = smem + wm * (SL * FRAG_BYTES) + lane * 16;
-    const char *lb0 = smem + (2 + wn) * (SL * FRAG_BYTES) + lane * 16;
+    const char *lb0 = smem + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
     for (uint32_t it = 0; it < nk; it++) {
       if (it + 1 < nk)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs 
     koff = koff + 1 == nk ? 0 : koff + 1;
     if (it + 1 < nk) stage(cur ^ 1, p.kb0 + koff);
     const char *la = smem + cur * STAGE_BYTES + wm * (SL * FRAG_BYTES) + lane * 16;
-    const char *lb = smem + cur * STAGE_BYTES + (2 + wn) * (SL * FRAG_BYTES) + lane * 16;
+    const char *lb = smem + cur * STAGE_BYTES + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
     if constexpr (ABL == VAR_MFMA_ONLY) {
 #pragma unroll
       for (int i = 0; i < SL; i++)
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void slice_gemm_kernel(const SliceGemmArgs 
   } // !VAR_PF2
 
   // ---- epilogue ------------------------------------------------------------------------------------
-  const uint32_t m = tm * 64 + wm * 32 + (lane & 31);
+  const uint32_t m = tm * (32 * WM) + wm * 32 + (lane & 31);
   const uint32_t nbase = tn * 64 + wn * 32 + 4 * (lane >> 5);
   if (p.dump) { // test hook: raw INT32 diagonal sums, [ND][N][M]
 #pragma unroll

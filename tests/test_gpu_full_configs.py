@@ -1,0 +1,134 @@
+"""GPU tests at BASELINE.json's full sizes (configs C2..C5), through size-independent properties:
+
+* sampled relative residual against a long-double product (mateval's metric, test/main_test.cu:101-117);
+* exact scaling: op(A) scaled by a power of two per row (B per column) scales C exactly -- the slices of a row
+  do not depend on its exponent, so the results must agree BITWISE after rescaling;
+* row equivariance: permuting rows of op(A) permutes rows of C bitwise (rows are cut independently and the
+  INT8 products are exact);
+* accuracy versus slice count: the residual falls ~2^-7 per slice until FP64 rounding saturates it
+  (BASELINE.md §2), and the auto mode picks the slice count the oracle picks.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_rand(shape, seed, lo=-1.0, hi=1.0):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.rand(shape, dtype=torch.float64, device="cuda", generator=g) * (hi - lo) + lo
+
+
+def _gemm(oz, h, op_a, op_b, m, n, k, A, B, C, mode, alpha=1.0, beta=0.0):
+    import torch
+    lda, ldb = A.shape[1], B.shape[1]
+    st = oz.gemm(h, op_a, op_b, m, n, k, alpha, A, lda, B, ldb, beta, C, m, mode)
+    torch.cuda.synchronize()
+    assert st == 0
+    return C
+
+
+def _residual(op_a, op_b, m, n, k, A, B, C, ns=1024):
+    return O.relative_residual_sampled(op_a, op_b, m, n, k, A.cpu().numpy().T, B.cpu().numpy().T,
+                                       C.cpu().numpy().T, ns=ns)
+
+
+def test_c2_fp64_int8_9_8192(oz):
+    """BASELINE configs[1]: the headline workload"""
+    import torch
+    m_, h = oz
+    n = 8192
+    A = _dev_rand((n, n), 1)   # (k, m) row-major == column-major m x k
+    B = _dev_rand((n, n), 2)
+    C = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    _gemm(m_, h, "N", "N", n, n, n, A, B, C, "fp64_int8_9")
+    r = _residual("N", "N", n, n, n, A, B, C)
+    assert r < 1e-15, r                                   # the reference's gate; measured ~9e-17
+    # exact scaling: row i of A times 2^(i%37 - 18), column j of B times 2^(j%29 - 14)
+    # exact powers of two (torch.pow on the GPU is not exact): built with ldexp on the host
+    ea = torch.from_numpy(np.ldexp(1.0, np.arange(n) % 37 - 18)).cuda()
+    eb = torch.from_numpy(np.ldexp(1.0, np.arange(n) % 29 - 14)).cuda()
+    A2 = A * ea[None, :]                                  # A stored (k, m): scale along m
+    B2 = B * eb[:, None]                                  # B stored (n, k): scale along n
+    C2 = torch.empty_like(C)
+    _gemm(m_, h, "N", "N", n, n, n, A2, B2, C2, "fp64_int8_9")
+    assert torch.equal(C2, C * ea[None, :] * eb[:, None])  # C stored (n, m)
+    # row equivariance
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    A3 = A[:, perm].contiguous()
+    C3 = torch.empty_like(C)
+    _gemm(m_, h, "N", "N", n, n, n, A3, B, C3, "fp64_int8_9")
+    assert torch.equal(C3, C[:, perm])
+
+
+def test_c3_slice_sweep_4096_wide_exponent(oz):
+    """BASELINE configs[2]: fp64_int8_{3..18}, N=4096, entries u*10^(8w)"""
+    import torch
+    m_, h = oz
+    n = 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    def wide():
+        u = torch.rand((n, n), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+        w = torch.rand((n, n), dtype=torch.float64, device="cuda", generator=g)
+        return u * torch.pow(torch.tensor(10.0, dtype=torch.float64, device="cuda"), 8 * w)
+    A, B = wide(), wide()
+    C = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    a_h, b_h = A.cpu().numpy().T, B.cpu().numpy().T
+    res = {}
+    for S in range(3, 19):
+        _gemm(m_, h, "N", "N", n, n, n, A, B, C, f"fp64_int8_{S}")
+        res[S] = O.relative_residual_sampled("N", "N", n, n, n, a_h, b_h, C.cpu().numpy().T, ns=512)
+    for S in range(3, 9):                                  # ~2^-7 per slice while truncation dominates
+        assert 30 < res[S] / res[S + 1] < 500, (S, res)
+    assert res[3] < 1e-3 and res[9] < 1e-15
+    for S in range(10, 19):                                # saturated: identical FP64 rounding floor
+        assert res[S] < 3e-16
+    C_native = torch.empty_like(C)
+    assert m_.native_dgemm(h, "N", "N", n, n, n, 1.0, A, n, B, n, 0.0, C_native, n) == 0
+    torch.cuda.synchronize()
+    r_native = O.relative_residual_sampled("N", "N", n, n, n, a_h, b_h, C_native.cpu().numpy().T, ns=512)
+    assert res[10] <= r_native                             # >= 10 slices: at least as accurate as native DGEMM
+
+
+def test_c4_auto_mode_16384_graded(oz):
+    """BASELINE configs[3]: fp64_int8_auto, N=16384, A column-graded over 10 decades (cond ~1e10), threshold 1.5"""
+    import torch
+    m_, h = oz
+    n = 16384
+    A = _dev_rand((n, n), 7)                               # stored (k, m): grade along k
+    A *= torch.pow(10.0, -10.0 * torch.arange(n, device="cuda").double() / (n - 1))[:, None]
+    B = _dev_rand((n, n), 8)
+    mode = m_.auto_mode_select(h, "N", "N", n, n, n, A, n, B, n, m_.real, 1.5)
+    # oracle on a sub-problem with the same statistics (rows are i.i.d.): leading 2048 rows / columns
+    s_ref, _ = O.auto_select("N", "N", 2048, 2048, n, np.asfortranarray(A[:, :2048].cpu().numpy().T),
+                             np.asfortranarray(B[:2048, :].cpu().numpy().T), 1.5)
+    assert m_.get_num_split(mode) == s_ref == 11           # graded A -> fp64_int8_11
+    m_.set_auto_mantissa_loss_threashold(h, 1.5)
+    C = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    _gemm(m_, h, "N", "N", n, n, n, A, B, C, "fp64_int8_auto")
+    r = _residual("N", "N", n, n, n, A, B, C, ns=512)
+    assert r < 1e-15, r
+    m_.set_auto_mantissa_loss_threashold(h, 0.0)
+
+
+def test_c5_hpl_panel_32768_k1024_nt(oz):
+    """BASELINE configs[4]: fp64_int8_9, M=N=32768, K=1024, transA=N transB=T"""
+    import torch
+    m_, h = oz
+    m = n = 32768
+    k = 1024
+    A = _dev_rand((k, m), 11)                              # A is m x k, lda = m
+    B = _dev_rand((k, n), 12)                              # op T: B stored n x k, ldb = n
+    C = torch.empty((n, m), dtype=torch.float64, device="cuda")
+    _gemm(m_, h, "N", "T", m, n, k, A, B, C, "fp64_int8_9")
+    r = O.relative_residual_sampled("N", "T", m, n, k, A.cpu().numpy().T, B.cpu().numpy().T, C.cpu().numpy().T, ns=2048)
+    assert r < 1e-15, r
+    # beta path at full size: C <- 0.5*A*B^T + 2*C must equal 2.5x the product up to one rounding per element
+    C2 = C.clone()
+    _gemm(m_, h, "N", "T", m, n, k, A, B, C2, "fp64_int8_9", alpha=0.5, beta=2.0)
+    assert torch.equal(C2, 2.5 * C)                        # powers of two and 2.5x: fma(0.5, x, 2x) == 2.5x exactly

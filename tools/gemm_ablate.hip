@@ -38,18 +38,20 @@ __global__ void fill_planes(int8_t *p, size_t n, unsigned seed) {
   }
 }
 
-template <int S, int VAR>
-static float run(const SliceGemmArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  constexpr size_t lds = 2 * 4 * S * FRAG_BYTES;
+template <int S, int VAR, int WM = 2>
+static float run(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  constexpr size_t lds = 2 * (WM + 2) * S * FRAG_BYTES;
+  SliceGemmArgs a = a0;
+  a.tiles_m = (a.M + 32 * WM - 1) / (32 * WM);
   static bool done = false;
   if (!done) {
-    CK(hipFuncSetAttribute((const void *)slice_gemm_kernel<S, 0, S, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                           (int)lds));
+    CK(hipFuncSetAttribute((const void *)slice_gemm_kernel<S, 0, S, VAR, WM>,
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
   }
   CK(hipMemsetAsync(a.phase, 0, 8 * 256, st));
   CK(hipEventRecord(e0, st));
-  hipLaunchKernelGGL((slice_gemm_kernel<S, 0, S, VAR>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((slice_gemm_kernel<S, 0, S, VAR, WM>), dim3(a.tiles_m * a.tiles_n), dim3(128 * WM), lds, st, a);
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -112,37 +114,17 @@ int main(int argc, char **argv) {
     std::vector<float> ms;
   };
   std::vector<Var> vars = {
-      {"baseline", run<S, 0>, false, {}},
-      {"baseline, no phase hint", run<S, 0>, true, {}},
-      {"pf2", run<S, VAR_PF2>, false, {}},
-      {"pf2 + publish every step", run<S, VAR_PF2 | VAR_PH_EVERY>, false, {}},
-      {"pf2 + every step + lead 2", run<S, VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2>, false, {}},
-      {"baseline + every step", run<S, VAR_PH_EVERY>, false, {}},
-      {"global->regs (no LDS write)", run<S, VAR_GLOBAL_TO_REG>, false, {}},
-      {"global->LDS, no sync", run<S, VAR_GLOBAL_NO_SYNC>, false, {}},
-      {"no-global (lds+mfma)", run<S, VAR_NO_GLOBAL>, false, {}},
+      {"shipped 64x64 (pf2+hint)", run<S, VAR_SHIPPED>, false, {}},
+      {"64x64 pf1 + hint", run<S, VAR_PH_EVERY | VAR_PH_LEAD2>, false, {}},
+      {"128x64 pf1 + hint", run<S, VAR_PH_EVERY | VAR_PH_LEAD2, 4>, false, {}},
+      {"128x64 pf2 + hint", run<S, VAR_SHIPPED, 4>, false, {}},
+      {"128x64 no-global", run<S, VAR_NO_GLOBAL, 4>, false, {}},
+      {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
       {"mfma-only", run<S, VAR_MFMA_ONLY>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
     for (auto &v : vars) {
-      SliceGemmArgs b = a;
-      if (v.nophase) b.phase = nullptr;
-      b.phase = v.nophase ? nullptr : phase;
-      if (v.nophase) { // run<> memsets a.phase: keep a valid pointer for the memset, null for the kernel
-        SliceGemmArgs c = a;
-        (void)c;
-      }
-      float ms;
-      if (v.nophase) {
-        CK(hipEventRecord(e0, st));
-        constexpr size_t lds = 2 * 4 * S * FRAG_BYTES;
-        hipLaunchKernelGGL((slice_gemm_kernel<S, 0, S, 0>), dim3(b.tiles_m * b.tiles_n), dim3(256), lds, st, b);
-        CK(hipEventRecord(e1, st));
-        CK(hipEventSynchronize(e1));
-        CK(hipEventElapsedTime(&ms, e0, e1));
-      } else {
-        ms = v.fn(b, st, e0, e1);
-      }
+      const float ms = v.fn(a, st, e0, e1);
       if (r > 0) v.ms.push_back(ms);
     }
   { // correctness of the candidate loop against the baseline loop (bitwise on C)
@@ -150,11 +132,16 @@ int main(int argc, char **argv) {
     run<S, 0>(a, st, e0, e1);
     CK(hipMemcpy(c0.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
     CK(hipMemset(C, 0xFF, 8 * M * N));
-    run<S, VAR_PF2>(a, st, e0, e1);
-    CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
-    size_t bad = 0;
-    for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
-    std::printf("check prefetch-2 vs baseline: %zu mismatching elements of %zu\n", bad, M * N);
+    for (int which = 0; which < 3; which++) {
+      CK(hipMemset(C, 0xFF, 8 * M * N));
+      if (which == 0) run<S, VAR_SHIPPED>(a, st, e0, e1);
+      if (which == 1) run<S, VAR_PH_EVERY | VAR_PH_LEAD2, 4>(a, st, e0, e1);
+      if (which == 2) run<S, VAR_SHIPPED, 4>(a, st, e0, e1);
+      CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
+      std::printf("check variant %d vs plain loop: %zu mismatching elements of %zu\n", which, bad, M * N);
+    }
   }
   const double ops = 45.0 * 2.0 * M * N * K;
   std::printf("N=%zu S=%d rounds=%d  (TOPS = 45*2*N^3 / t)\n", N, S, rounds);

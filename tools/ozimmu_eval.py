@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""tools/ozimmu_eval.py — the reference's accuracy + throughput harness (test/main_test.cu) for this build.
+
+Same sub-commands and the same CSV line (test/main_test.cu:143-151, 658-659):
+
+    gpu,gemm,input,mode,opA,opB,m,n,k,residual,max_relative,throughput_in_tflops
+
+    python tools/ozimmu_eval.py ci_test                                   # test/main_test.cu:702-746 (real part)
+    python tools/ozimmu_eval.py urand01 dgemm seq 1024 4096 1024 fp64_int8_6 fp64_int8_9 dgemm
+    python tools/ozimmu_eval.py exp_rand-2 dgemm exp2 10 13 1 fp64_int8_9   # sizes 2^10 .. 2^13
+    python tools/ozimmu_eval.py wide-8 dgemm seq 4096 4096 1 $(for s in $(seq 3 18); do echo fp64_int8_$s; done)
+
+Inputs (device generated, seed 0 like test/main_test.cu:15): urand01 = U(0,1]; normal01 = N(0,1);
+exp_rand-PHI = (u-0.5)*exp(PHI*randn) (test/main_test.cu:56-70); wide-D = u*10^(D*w) (BASELINE config 3).
+Residual = ||C - C_true||_F / ||C_true||_F and max relative error on 2048 sampled entries against a long-double
+product (the un-vendored mateval computes the same metrics against an FP64 device product).  Timing:
+1 warm-up + `--reps` back-to-back calls between device synchronisations (reference: 100).
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def gen(kind, shape, gen_):
+    import torch
+    if kind == "urand01":
+        return 1.0 - torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen_)
+    if kind == "normal01":
+        return torch.randn(shape, dtype=torch.float64, device="cuda", generator=gen_)
+    if kind.startswith("exp_rand-"):
+        phi = float(kind.split("-", 1)[1])
+        u = torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen_)
+        z = torch.randn(shape, dtype=torch.float64, device="cuda", generator=gen_)
+        return (u - 0.5) * torch.exp(phi * z)
+    if kind.startswith("wide-"):
+        d = float(kind.split("-", 1)[1])
+        u = torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen_) * 2 - 1
+        w = torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen_)
+        return u * torch.pow(torch.tensor(10.0, dtype=torch.float64, device="cuda"), d * w)
+    raise SystemExit(f"unknown input mode {kind}")
+
+
+def eval_one(oz, O, h, kind, op_a, op_b, m, n, k, mode, reps, threshold=0.0, gpu_name="MI355X"):
+    import numpy as np
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    a_shape = (k, m) if op_a == "N" else (m, k)   # (cols, ld): column-major storage
+    b_shape = (n, k) if op_b == "N" else (k, n)
+    A = gen(kind, a_shape, g)
+    B = gen(kind, b_shape, g)
+    C = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+    lda, ldb, ldc = a_shape[1], b_shape[1], m
+
+    def call():
+        if mode == "dgemm":
+            st = oz.native_dgemm(h, op_a, op_b, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc)
+        else:
+            st = oz.gemm(h, op_a, op_b, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc, mode)
+        if st:
+            raise RuntimeError(f"gemm status {st}")
+    call()
+    torch.cuda.synchronize()
+    a_h, b_h, c_h = A.cpu().numpy().T, B.cpu().numpy().T, C.cpu().numpy().T
+    rng = np.random.default_rng(1)
+    rows = rng.integers(0, m, 2048)
+    cols = rng.integers(0, n, 2048)
+    res = O.relative_residual_sampled(op_a, op_b, m, n, k, a_h, b_h, c_h, ns=2048, seed=1)
+    # max relative error on the same kind of sample (long double truth)
+    aa = (a_h[rows, :] if op_a == "N" else a_h[:, rows].T).astype(np.longdouble)
+    bb = (b_h[:, cols].T if op_b == "N" else b_h[cols, :]).astype(np.longdouble)
+    truth = (aa * bb).sum(axis=1)
+    got = c_h[rows, cols].astype(np.longdouble)
+    max_rel = float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), np.finfo(np.float64).tiny)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    tflops = 2.0 * m * n * k / dt / 1e12
+    print(f"{gpu_name},D,{kind},{mode},{op_a},{op_b},{m},{n},{k},{res:e},{max_rel:e},{tflops:e}", flush=True)
+    return res, tflops
+
+
+def main():
+    ap = argparse.ArgumentParser(add_help=True)
+    ap.add_argument("args", nargs="+")
+    ap.add_argument("--reps", type=int, default=20)
+    ns = ap.parse_args()
+    argv = ns.args
+    import torch
+    import ozimmu_amd as oz
+    from oracle import oracle as O
+    name = torch.cuda.get_device_name(0).replace(" ", "_")
+    h = oz.create()
+    oz.set_cuda_stream(h, torch.cuda.current_stream())
+    print("gpu,gemm,input,mode,opA,opB,m,n,k,residual,max_relative,throughput_in_tflops")
+    try:
+        if argv[0] == "ci_test":
+            # test/main_test.cu:702-746, real half: ops {N,T}^2 x {1023,1024,1025}^3 x fp64_int8_8..16, threshold 1e-15
+            passed = total = 0
+            for op_a in "NT":
+                for op_b in "NT":
+                    for m in (1023, 1024, 1025):
+                        for n in (1023, 1024, 1025):
+                            for k in (1023, 1024, 1025):
+                                for s in range(8, 17):
+                                    r, _ = eval_one(oz, O, h, "urand01", op_a, op_b, m, n, k, f"fp64_int8_{s}", 1,
+                                                    gpu_name=name)
+                                    total += 1
+                                    if r < 1e-15:
+                                        passed += 1
+                                    else:
+                                        print("^^^ FAILED ^^^^")
+            print(f"PASSED {passed:5d} / {total:5d}")
+            sys.exit(0 if passed == total else 1)
+        kind, gemm, seq, start, end, step = argv[0], argv[1], argv[2], int(argv[3]), int(argv[4]), int(argv[5])
+        if gemm != "dgemm":
+            raise SystemExit("only dgemm (real) is implemented; zgemm is the next row (DESIGN.md)")
+        modes = argv[6:]
+        sizes = [1 << e for e in range(start, end + 1, step)] if seq == "exp2" else list(range(start, end + 1, step))
+        for nsz in sizes:
+            for mode in modes:
+                eval_one(oz, O, h, kind, "N", "N", nsz, nsz, nsz, mode, ns.reps, gpu_name=name)
+    finally:
+        torch.cuda.synchronize()
+        oz.destroy(h)
+
+
+if __name__ == "__main__":
+    main()
