@@ -7,7 +7,7 @@
 
 namespace ozhip {
 
-constexpr int SINGLE_PASS_MAX_S = 10; // register budget: 16*S accumulators + 4*S B-fragments <= ~210 VGPRs
+constexpr int SINGLE_PASS_MAX_S = 12; // register budget: 16*S accumulators + 4*S B-fragments + 2 A-fragments <= 256 VGPRs
 
 struct SliceGemmArgs {
   const int8_t *a_planes; // tiled planes of op(A): rows = M (layout.h)

@@ -27,22 +27,30 @@
 namespace ozhip {
 
 template <int S, int D0, int ND>
-static hipError_t launch_one(const SliceGemmArgs &a, hipStream_t stream) {
+static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
-  constexpr size_t lds = 2 * 4 * SL * FRAG_BYTES;
+  // Workgroup shape.  Up to 10 staged slices: 4 waves / 64x64, two workgroups per CU (they cover each other's
+  // LDS-read phases).  11..13 staged slices do not fit twice in 160 KiB of LDS: one 8-wave 128x64 workgroup per CU
+  // (2*(4+2)*SL KiB).  More than 13 (second pass of S >= 14): back to 64x64, one workgroup per CU.
+  constexpr int WM = (SL >= 11 && SL <= 13) ? 4 : 2;
+  constexpr size_t lds = 2 * (WM + 2) * SL * FRAG_BYTES;
   // the prefetch-2 loop keeps all 2*SL fragments in registers next to the 16*ND accumulators: beyond
-  // ~232 of the 256 VGPRs (2 waves/SIMD) it would spill inside the k loop, so those passes (second pass
-  // of S >= 16) stream the A fragments instead (prefetch distance 1).
-  constexpr int VAR_PRODUCTION = (16 * ND + 8 * SL <= 232) ? VAR_SHIPPED : (VAR_SHIPPED & ~VAR_PF2);
+  // ~232 of the 256 VGPRs (2 waves/SIMD) it would spill inside the k loop, and with one 8-wave workgroup per CU
+  // its LDS read burst is exposed (tools/gemm_ablate.hip: 24.3 vs 19.6 ms): those cases stream the A fragments
+  // (prefetch distance 1).
+  constexpr int VAR_PRODUCTION = (WM == 2 && 16 * ND + 8 * SL <= 232) ? VAR_SHIPPED : (VAR_SHIPPED & ~VAR_PF2);
+  SliceGemmArgs a = a0;
+  a.tiles_m = (a.M + 32 * WM - 1) / (32 * WM);
+  a.tiles_n = (a.N + 63) / 64;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION>,
+    hipError_t e = hipFuncSetAttribute((const void *)slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const uint32_t nb = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION>), dim3(nb), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>), dim3(nb), dim3(128 * WM), lds, stream, a);
   return hipGetLastError();
 }
 
