@@ -28,6 +28,7 @@ struct SliceGemmArgs {
   uint32_t *phase; // 8 advisory words (one per XCD): k-block the XCD's workgroups are at; zeroed per call
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue
+  unsigned long long *trace; // development only (tools/gemm_ablate.hip, VAR_TRACE)
 };
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);

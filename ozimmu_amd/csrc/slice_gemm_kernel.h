@@ -27,8 +27,12 @@ constexpr int VAR_PF2 = 8;            // main loop with prefetch distance 2 (fra
 constexpr int VAR_NO_CU_SWIZZLE = 16; // plain (p%8, p/8) tile order inside a patch
 constexpr int VAR_PH_EVERY = 32;      // publish the phase hint every k-step
 constexpr int VAR_PH_LEAD2 = 64;      // late joiners start 2 k-steps ahead of the published phase
+constexpr int VAR_SADDR = 1024;       // staging: one address + M0 per 3 fragment blocks, immediate offsets 0/1024/2048
+constexpr int VAR_SETPRIO = 128;      // s_setprio(1) around the MFMA burst of the prefetch-2 loop
+constexpr int VAR_TRACE = 512;        // record shader-clock stamps (SliceGemmArgs::trace), development only
+constexpr int VAR_INTERLEAVE = 256;   // prefetch-2 loop: issue the refill copies one per A-slice between the MFMAs
 // what the library ships (tools/gemm_ablate.hip A/B, N=8192 S=9: 18.9 ms vs 20.0 ms for VAR=0)
-constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2;
+constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2 | VAR_SADDR;
 
 // 2^e as a double, e in the normal range
 __device__ __forceinline__ double pow2d(int e) {
@@ -90,6 +94,8 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   const int8_t *src = (wave < WM) ? p.a_planes + (size_t)(WM * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
                                   : p.b_planes + (size_t)(2 * tn + (wave - WM)) * p.KB * (size_t)(S * FRAG_BYTES);
   const bool stager = wave < WM + 2; // WM = 4: waves 6,7 stage nothing
+  const int8_t *src_u = src;                 // wave-uniform part (SGPRs)
+  const uint32_t lane_off = (uint32_t)lane * 16u; // per-lane part (one VGPR)
   src += lane * 16;
   v4i regstage[SL]; // VAR_GLOBAL_TO_REG only
   auto stage = [&](int buf, uint32_t kb) {
@@ -103,8 +109,28 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     }
     if constexpr (ABL != 0 && ABL != VAR_GLOBAL_NO_SYNC) return;
     if (!stager) return;
-    const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
     char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
+    if constexpr ((VAR & VAR_SADDR) != 0) {
+      // scalar base (SGPR pair) + one 32-bit lane offset VGPR, and the instruction's immediate offset walks
+      // 4 consecutive fragment blocks (it advances the LDS address too): 3 address/M0 set-ups per stage, not 9
+      const int8_t *gu = src_u + (size_t)kb * (S * FRAG_BYTES);
+#pragma unroll
+      for (int s = 0; s < SL; s++) {
+        constexpr int G = 3; // blocks per immediate-offset group: offsets 0, 1024, 2048 (< 4096)
+        const int g0 = s / G * G;
+        if (s % G == 0)
+          __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + g0 * FRAG_BYTES + lane_off),
+                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 0, 0);
+        else if (s % G == 1)
+          __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + g0 * FRAG_BYTES + lane_off),
+                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 1024, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + g0 * FRAG_BYTES + lane_off),
+                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 2048, 0);
+      }
+      return;
+    }
+    const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
 #pragma unroll
     for (int s = 0; s < SL; s++)
       __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(g + s * FRAG_BYTES),
@@ -164,35 +190,60 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     const char *la0 = smem + wm * (SL * FRAG_BYTES) + lane * 16;
     const char *lb0 = smem + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
     for (uint32_t it = 0; it < nk; it++) {
+      // development trace (VAR_TRACE): shader-clock stamps of one wave per workgroup for 16 k-steps
+      const bool tr = (VAR & VAR_TRACE) != 0 && p.trace && it >= 64 && it < 80 && lane == 0 && blockIdx.x < 64;
+      unsigned long long *trp = tr ? p.trace + ((size_t)(blockIdx.x * 8 + wave) * 16 + (it - 64)) * 8 : nullptr;
+      if (tr) trp[0] = clock64();
       if (it + 1 < nk)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tr) trp[1] = clock64();
       __builtin_amdgcn_s_barrier(); // stage `it` is in LDS for every wave
       asm volatile("" ::: "memory");
+      if (tr) trp[2] = clock64();
       v4i bf[SL], af[SL];
 #pragma unroll
       for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb0 + cur * STAGE_BYTES + j * FRAG_BYTES);
 #pragma unroll
       for (int i = 0; i < SL; i++) af[i] = *(const v4i *)(la0 + cur * STAGE_BYTES + i * FRAG_BYTES);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (tr) trp[3] = clock64();
       __builtin_amdgcn_s_barrier(); // every wave holds its fragments: buffer `cur` is free
       asm volatile("" ::: "memory");
+      if (tr) trp[4] = clock64();
       if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
         __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       koff = koff_next(koff);
-      if (it + 2 < nk) {
-        stage(cur, p.kb0 + k_issue);
-        k_issue = koff_next(k_issue);
+      const bool refill = it + 2 < nk;
+      if constexpr ((VAR & VAR_INTERLEAVE) == 0) {
+        if (refill) stage(cur, p.kb0 + k_issue);
       }
+      if (tr) trp[5] = clock64();
+      if constexpr ((VAR & VAR_SETPRIO) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < SL; i++)
+      for (int i = 0; i < SL; i++) {
+        if constexpr ((VAR & VAR_INTERLEAVE) != 0) {
+          // one 1 KiB LDS-DMA per A-slice row of MFMAs: the copies trickle into the texture path while the
+          // matrix pipe works, instead of 4..8 waves queueing 9 copies each behind the barrier
+          if (refill && stager && ABL == 0) {
+            const int8_t *g = src + (size_t)(p.kb0 + k_issue) * (S * FRAG_BYTES) + i * FRAG_BYTES;
+            char *l = smem + cur * STAGE_BYTES + wave * (SL * FRAG_BYTES) + i * FRAG_BYTES;
+            __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)g, (OZ_AS3 void *)l, 16, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < SL; j++) {
           const int d = i + j;
           if (d >= D0 && d < D0 + ND && d <= S - 1)
             acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[d - D0], 0, 0, 0);
         }
+        if constexpr ((VAR & VAR_INTERLEAVE) != 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (refill) k_issue = koff_next(k_issue);
+      if (tr) trp[6] = clock64();
+      if constexpr ((VAR & VAR_SETPRIO) != 0) __builtin_amdgcn_s_setprio(0);
       cur ^= 1;
     }
   } else {

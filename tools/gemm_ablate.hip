@@ -115,12 +115,8 @@ int main(int argc, char **argv) {
   };
   std::vector<Var> vars = {
       {"shipped 64x64 (pf2+hint)", run<S, VAR_SHIPPED>, false, {}},
-      {"64x64 pf1 + hint", run<S, VAR_PH_EVERY | VAR_PH_LEAD2>, false, {}},
-      {"128x64 pf1 + hint", run<S, VAR_PH_EVERY | VAR_PH_LEAD2, 4>, false, {}},
-      {"128x64 pf2 + hint", run<S, VAR_SHIPPED, 4>, false, {}},
-      {"128x64 no-global", run<S, VAR_NO_GLOBAL, 4>, false, {}},
+      {"shipped + saddr/imm", run<S, VAR_SHIPPED | VAR_SADDR>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
-      {"mfma-only", run<S, VAR_MFMA_ONLY>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
     for (auto &v : vars) {
@@ -135,13 +131,39 @@ int main(int argc, char **argv) {
     for (int which = 0; which < 3; which++) {
       CK(hipMemset(C, 0xFF, 8 * M * N));
       if (which == 0) run<S, VAR_SHIPPED>(a, st, e0, e1);
-      if (which == 1) run<S, VAR_PH_EVERY | VAR_PH_LEAD2, 4>(a, st, e0, e1);
-      if (which == 2) run<S, VAR_SHIPPED, 4>(a, st, e0, e1);
+      if (which == 1) run<S, VAR_SHIPPED | VAR_SADDR>(a, st, e0, e1);
+      if (which == 2) run<S, VAR_SHIPPED | VAR_INTERLEAVE, 4>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
       for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
       std::printf("check variant %d vs plain loop: %zu mismatching elements of %zu\n", which, bad, M * N);
     }
+  }
+  { // per-phase trace of the shipped loop
+    unsigned long long *tr;
+    const size_t ntr = 64 * 8 * 16 * 8;
+    CK(hipMalloc(&tr, ntr * 8));
+    CK(hipMemset(tr, 0, ntr * 8));
+    SliceGemmArgs b = a;
+    b.trace = tr;
+    run<S, VAR_SHIPPED | VAR_SADDR | VAR_TRACE>(b, st, e0, e1);
+    std::vector<unsigned long long> h(ntr);
+    CK(hipMemcpy(h.data(), tr, ntr * 8, hipMemcpyDeviceToHost));
+    const char *names[6] = {"wait vmcnt", "barrier A", "frag reads", "barrier B", "stage issue", "45 MFMA issue"};
+    double sum[6] = {0}, tot = 0;
+    int cnt = 0;
+    for (int blk = 0; blk < 64; blk++)
+      for (int w = 0; w < 4; w++)
+        for (int it = 0; it < 15; it++) {
+          const unsigned long long *t = &h[((size_t)(blk * 8 + w) * 16 + it) * 8];
+          const unsigned long long *tn = t + 8;
+          if (!t[0] || !tn[0]) continue;
+          for (int k = 0; k < 6; k++) sum[k] += (double)(t[k + 1] - t[k]);
+          tot += (double)(tn[0] - t[0]);
+          cnt++;
+        }
+    std::printf("trace (s_memtime ticks per k-step, mean over %d samples): total %.0f\n", cnt, tot / cnt);
+    for (int k = 0; k < 6; k++) std::printf("   %-14s %8.0f\n", names[k], sum[k] / cnt);
   }
   const double ops = 45.0 * 2.0 * M * N * K;
   std::printf("N=%zu S=%d rounds=%d  (TOPS = 45*2*N^3 / t)\n", N, S, rounds);
