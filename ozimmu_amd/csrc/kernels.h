@@ -29,6 +29,7 @@ struct SliceGemmArgs {
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue
   unsigned long long *trace; // development only (tools/gemm_ablate.hip, VAR_TRACE)
+  uint32_t trace_block0;     // first traced workgroup id
 };
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);

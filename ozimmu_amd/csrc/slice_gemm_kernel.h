@@ -28,6 +28,8 @@ constexpr int VAR_NO_CU_SWIZZLE = 16; // plain (p%8, p/8) tile order inside a pa
 constexpr int VAR_PH_EVERY = 32;      // publish the phase hint every k-step
 constexpr int VAR_PH_LEAD2 = 64;      // late joiners start 2 k-steps ahead of the published phase
 constexpr int VAR_SADDR = 1024;       // staging: one address + M0 per 3 fragment blocks, immediate offsets 0/1024/2048
+constexpr int VAR_MUBUF = 2048;       // staging with buffer_load ... lds (SGPR resource) instead of global_load_lds
+constexpr int VAR_STATIC_PRIO = 4096; // odd/even workgroup generations get different s_setprio
 constexpr int VAR_SETPRIO = 128;      // s_setprio(1) around the MFMA burst of the prefetch-2 loop
 constexpr int VAR_TRACE = 512;        // record shader-clock stamps (SliceGemmArgs::trace), development only
 constexpr int VAR_INTERLEAVE = 256;   // prefetch-2 loop: issue the refill copies one per A-slice between the MFMAs
@@ -94,6 +96,10 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   const int8_t *src = (wave < WM) ? p.a_planes + (size_t)(WM * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
                                   : p.b_planes + (size_t)(2 * tn + (wave - WM)) * p.KB * (size_t)(S * FRAG_BYTES);
   const bool stager = wave < WM + 2; // WM = 4: waves 6,7 stage nothing
+  // MUBUF experiment: buffer resource over the whole plane, row-block offset as an SGPR
+  const int8_t *plane = (wave < WM) ? p.a_planes : p.b_planes;
+  const uint32_t plane_off = (uint32_t)(((wave < WM) ? (WM * tm + wave) : (2 * tn + (wave - WM))) * p.KB) * (uint32_t)(S * FRAG_BYTES);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)plane, 0, 0x7fffffff, 0x00020000);
   const int8_t *src_u = src;                 // wave-uniform part (SGPRs)
   const uint32_t lane_off = (uint32_t)lane * 16u; // per-lane part (one VGPR)
   src += lane * 16;
@@ -110,6 +116,15 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     if constexpr (ABL != 0 && ABL != VAR_GLOBAL_NO_SYNC) return;
     if (!stager) return;
     char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
+    if constexpr ((VAR & VAR_MUBUF) != 0) {
+      // MUBUF form: SGPR resource + one VGPR lane offset + SGPR byte offset (experiment: cheaper issue under MFMA load?)
+      const uint32_t so = plane_off + kb * (uint32_t)(S * FRAG_BYTES);
+#pragma unroll
+      for (int s = 0; s < SL; s++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, lane_off,
+                                             so + s * FRAG_BYTES, 0, 0);
+      return;
+    }
     if constexpr ((VAR & VAR_SADDR) != 0) {
       // scalar base (SGPR pair) + one 32-bit lane offset VGPR, and the instruction's immediate offset walks
       // 4 consecutive fragment blocks (it advances the LDS address too): 3 address/M0 set-ups per stage, not 9
@@ -172,6 +187,11 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   }
 
   int cur = 0;
+  if constexpr ((VAR & VAR_STATIC_PRIO) != 0) {
+    // the two workgroups of a CU share each SIMD's matrix pipe; give them different static priorities so that
+    // their MFMA bursts serialise (one computes while the other stages) instead of interleaving in phase
+    if (__builtin_amdgcn_readfirstlane((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(2);
+  }
   if constexpr ((VAR & VAR_PF2) != 0) {
     // ---- prefetch distance 2 on two LDS buffers ------------------------------------------------------
     // The HBM/L2 -> LDS stream is latency bound (Little: bytes in flight / latency): with one stage in
@@ -191,8 +211,9 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     const char *lb0 = smem + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
     for (uint32_t it = 0; it < nk; it++) {
       // development trace (VAR_TRACE): shader-clock stamps of one wave per workgroup for 16 k-steps
-      const bool tr = (VAR & VAR_TRACE) != 0 && p.trace && it >= 64 && it < 80 && lane == 0 && blockIdx.x < 64;
-      unsigned long long *trp = tr ? p.trace + ((size_t)(blockIdx.x * 8 + wave) * 16 + (it - 64)) * 8 : nullptr;
+      const uint32_t trb = blockIdx.x - p.trace_block0;
+      const bool tr = (VAR & VAR_TRACE) != 0 && p.trace && it >= 64 && it < 80 && lane == 0 && trb < 64;
+      unsigned long long *trp = tr ? p.trace + ((size_t)(trb * 8 + wave) * 16 + (it - 64)) * 8 : nullptr;
       if (tr) trp[0] = clock64();
       if (it + 1 < nk)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");

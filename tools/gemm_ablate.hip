@@ -114,8 +114,10 @@ int main(int argc, char **argv) {
     std::vector<float> ms;
   };
   std::vector<Var> vars = {
-      {"shipped 64x64 (pf2+hint)", run<S, VAR_SHIPPED>, false, {}},
-      {"shipped + saddr/imm", run<S, VAR_SHIPPED | VAR_SADDR>, false, {}},
+      {"shipped 64x64", run<S, VAR_SHIPPED>, false, {}},
+      {"shipped + static prio", run<S, VAR_SHIPPED | VAR_STATIC_PRIO>, false, {}},
+      {"MUBUF staging", run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>, false, {}},
+      {"MUBUF + static prio", run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF | VAR_STATIC_PRIO>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
@@ -131,7 +133,7 @@ int main(int argc, char **argv) {
     for (int which = 0; which < 3; which++) {
       CK(hipMemset(C, 0xFF, 8 * M * N));
       if (which == 0) run<S, VAR_SHIPPED>(a, st, e0, e1);
-      if (which == 1) run<S, VAR_SHIPPED | VAR_SADDR>(a, st, e0, e1);
+      if (which == 1) run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>(a, st, e0, e1);
       if (which == 2) run<S, VAR_SHIPPED | VAR_INTERLEAVE, 4>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
@@ -139,14 +141,18 @@ int main(int argc, char **argv) {
       std::printf("check variant %d vs plain loop: %zu mismatching elements of %zu\n", which, bad, M * N);
     }
   }
-  { // per-phase trace of the shipped loop
+  for (int which = 0; which < 4; which++) { // per-phase trace: {global, MUBUF} x {first round, mid-kernel}
     unsigned long long *tr;
     const size_t ntr = 64 * 8 * 16 * 8;
     CK(hipMalloc(&tr, ntr * 8));
     CK(hipMemset(tr, 0, ntr * 8));
     SliceGemmArgs b = a;
     b.trace = tr;
-    run<S, VAR_SHIPPED | VAR_SADDR | VAR_TRACE>(b, st, e0, e1);
+    b.trace_block0 = (which & 2) ? 8192 : 0;
+    if (which & 1)
+      run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF | VAR_STATIC_PRIO | VAR_TRACE>(b, st, e0, e1);
+    else
+      run<S, VAR_SHIPPED | VAR_TRACE>(b, st, e0, e1);
     std::vector<unsigned long long> h(ntr);
     CK(hipMemcpy(h.data(), tr, ntr * 8, hipMemcpyDeviceToHost));
     const char *names[6] = {"wait vmcnt", "barrier A", "frag reads", "barrier B", "stage issue", "45 MFMA issue"};
@@ -162,8 +168,11 @@ int main(int argc, char **argv) {
           tot += (double)(tn[0] - t[0]);
           cnt++;
         }
-    std::printf("trace (s_memtime ticks per k-step, mean over %d samples): total %.0f\n", cnt, tot / cnt);
-    for (int k = 0; k < 6; k++) std::printf("   %-14s %8.0f\n", names[k], sum[k] / cnt);
+    std::printf("trace %s, workgroups %u..: %.0f ticks per k-step (%d samples):", (which & 1) ? "MUBUF " : "global", b.trace_block0,
+                tot / cnt, cnt);
+    for (int k = 0; k < 6; k++) std::printf("  %s %.0f", names[k], sum[k] / cnt);
+    std::printf("\n");
+    CK(hipFree(tr));
   }
   const double ops = 45.0 * 2.0 * M * N * K;
   std::printf("N=%zu S=%d rounds=%d  (TOPS = 45*2*N^3 / t)\n", N, S, rounds);
