@@ -167,13 +167,24 @@ def main():
             "kernel": "slice_gemm_kernel (INT8 MFMA slice products + FP64 recombination epilogue)",
             "bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS,
             "unit": "TFLOP/s", "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4),
-            "traffic": None,
+            "traffic": None,  # filled below from the committed PMC summary of this very workload, if present
             "avg_kernel_ms": round(k_ms, 4),
             "algorithmic_int8_ops_per_launch": int8_ops,
             "split_ms": round(split_ms, 4),
             "split_share_of_call": round(split_ms / (split_ms + k_ms), 4),
             "split_algorithmic_GBps": round((8 + S) * (M * K + K * N) / (split_ms * 1e-3) / 1e9, 1),
         }
+
+        # HBM bytes per launch of that kernel: PMC counters cannot be read in-process; they come from the separate
+        # rocprofv3 --pmc passes of this same command (tools/profile.sh -> profiles/latest_traffic.json)
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if t.get("workload", "").startswith(f"{args.mode}, M={M} N={N} K={K}, op {opa}/{opb}"):
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)"
+                out["roofline"]["traffic_algorithmic_bytes"] = S * (M * K + K * N) + 8.0 * M * N
+                out["roofline"]["l2_hit_rate"] = round(t.get("l2_hit_rate", 0), 3)
 
         if not args.no_extra:
             from oracle import oracle as O
@@ -201,8 +212,9 @@ def main():
 
         if not args.no_cpu and world == 1:
             from oracle import oracle as O
-            # bounded sample of the same workload: the top-left 1024x1024 block of C over the full K
-            ms_, ns_ = min(M, 1024), min(N, 1024)
+            # bounded sample of the same workload: the leading block of C over the full K
+            blk = 2048 if O.max_threads() >= 64 else 1024   # ~10-30 s of CPU work
+            ms_, ns_ = min(M, blk), min(N, blk)
             a_h = A.cpu().numpy().T
             b_h = B.cpu().numpy().T
             a_s = np.asfortranarray(a_h[:ms_, :] if opa == "N" else a_h[:, :ms_])
@@ -215,7 +227,7 @@ def main():
                 "value": round(2.0 * ms_ * ns_ * K / dt / 1e12, 5), "unit": "TFLOP/s",
                 "cores": O.max_threads(), "kind": "port",
                 "sample": f"oracle (plain C + OpenMP port of the reference algorithm, reference summation order) on the "
-                          f"{ms_}x{ns_} leading block of C, full K={K}, {args.mode}: {dt:.1f} s",
+                          f"{ms_}x{ns_} leading block of C, full K={K}, {args.mode}: {dt:.1f} s of CPU time",
             }
             # north_star's CPU comparator: OpenBLAS DGEMM (numpy's bundled OpenBLAS), all host cores
             nb = min(N, 4096)

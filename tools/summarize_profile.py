@@ -8,7 +8,7 @@ import os
 import sys
 
 
-def main(src, dst):
+def main(src, dst, workload="fp64_int8_9, M=8192 N=8192 K=8192, op N/N"):
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
     with open(dst + "_kernel_stats.csv", "w", newline="") as f:
@@ -54,8 +54,23 @@ def main(src, dst):
             lines.append("- derived: write_GB = %.3f GB" % (c["WRITE_SIZE"] * 1024 / 1e9))
         lines.append("")
     open(dst + "_pmc.md", "w").write("\n".join(lines))
+    # machine-readable HBM traffic of the dominant kernel (bench.py reports it as roofline.traffic)
+    import json
+    best = None
+    for k in agg:
+        if "slice_gemm_kernel" in k and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+            c = {n: sum(v) / len(v) for n, v in agg[k].items()}
+            t = dict(kernel=k.split("(")[0], fetch_bytes_corrected=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024)
+            t["hbm_bytes_per_launch"] = t["fetch_bytes_corrected"] + t["write_bytes"]
+            t["l2_hit_rate"] = c.get("TCC_HIT_sum", 0) / max(c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0), 1)
+            t["workload"] = workload
+            t["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile.sh); FETCH_SIZE doubled (gfx950)"
+            if best is None or t["hbm_bytes_per_launch"] > best["hbm_bytes_per_launch"]:
+                best = t
+    if best:
+        json.dump(best, open(dst + "_traffic.json", "w"), indent=1)
     print("wrote", dst + "_kernel_stats.csv", dst + "_pmc.md")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
