@@ -12,6 +12,7 @@
  *      rocblas_dgemm, rocblas_dgemm_64                    <- cublasDgemm_v2 (src/cublas.cu:280-295)
  *      rocblas_gemm_ex (all-f64_r case)                   <- cublasGemmEx   (src/cublas.cu:133-278)
  *      rocblas_dgemm_strided_batched                      <- cublasDgemmStridedBatched (src/cublas.cu:474-492)
+ *      rocblas_zgemm, rocblas_gemm_ex (all-f64_c case)    <- cublasZgemm_v2 (src/cublas.cu:297-313)
  *      hipblasDgemm, hipblasGemmEx (HIP_R_64F case)       <- same, for applications that bind hipBLAS
  *                                                            directly (hipBLAS itself calls rocblas_dgemm)
  *
@@ -95,7 +96,8 @@ size_t ozimmu_hip_working_memory_size(ozimmu_operation_t op_A, ozimmu_operation_
                                       ozimmu_compute_mode_t compute_mode);
 
 /* ozimmu.hpp:75-82 (src/gemm.cu:524-653).  0 ok; 1 invalid shape / alignment (src/gemm.cu:554-556);
- * 2 unsupported (complex: next row F1); 3 HIP failure (the reference would throw). */
+ * 2 unsupported mode value; 3 HIP failure (the reference would throw).  element_kind OZIMMU_COMPLX: a, b, c are
+ * interleaved double-complex, alpha/beta point to {re, im} (gemm_int8<cuDoubleComplex>, src/gemm.cu:412-521). */
 int ozimmu_hip_gemm(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
                     size_t n, size_t k, const void *alpha, const void *a_ptr, size_t lda, const void *b_ptr,
                     size_t ldb, const void *beta, void *c_ptr, size_t ldc,

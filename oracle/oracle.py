@@ -179,3 +179,48 @@ def relative_residual_sampled(op_a, op_b, m, n, k, a, b, c, ns=2048, seed=1234):
 
 def max_threads():
     return int(lib().oz_oracle_max_threads())
+
+
+# ---- complex (ZGEMM) ------------------------------------------------------------------------------------
+
+def _zld(a):
+    """leading dimension (complex elements) of a column-major 2-D complex128 array or view"""
+    assert a.dtype == np.complex128 and a.ndim == 2 and a.strides[0] == 16, "need column-major complex128"
+    return max(a.strides[1] // 16, 1) if a.shape[1] > 1 else max(a.shape[0], 1)
+
+
+def zgemm(op_a, op_b, m, n, k, alpha, a, b, beta, c, S, order=ORDER_REFERENCE, kchunk=0, quirks=0):
+    """In place on c (column-major complex128).  Restates gemm_int8<cuDoubleComplex> (src/gemm.cu:412-521)."""
+    L = lib()
+    L.oz_oracle_zgemm.restype = C.c_int
+    L.oz_oracle_zgemm.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                  C.c_int, C.c_size_t, C.c_int]
+    al = np.array([complex(alpha).real, complex(alpha).imag])
+    be = np.array([complex(beta).real, complex(beta).imag])
+    return int(L.oz_oracle_zgemm(op_code(op_a), op_code(op_b), m, n, k, _p(al), _p(a), _zld(a), _p(b), _zld(b),
+                                 _p(be), _p(c), _zld(c), S, order, kchunk, quirks))
+
+
+def auto_select_z(op_a, op_b, m, n, k, a, b, threshold):
+    L = lib()
+    L.oz_oracle_auto_select_z.restype = C.c_int
+    L.oz_oracle_auto_select_z.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                          C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
+    cnt = np.zeros(16, dtype=np.uint64)
+    s = L.oz_oracle_auto_select_z(op_code(op_a), op_code(op_b), m, n, k, _p(a), _zld(a), _p(b), _zld(b),
+                                  float(threshold), _p(cnt))
+    return int(s), cnt
+
+
+def relative_residual_sampled_z(op_a, op_b, m, n, k, a, b, c, ns=2048, seed=1234):
+    L = lib()
+    L.oz_oracle_relative_residual_sampled_z.restype = C.c_double
+    L.oz_oracle_relative_residual_sampled_z.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                        C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(seed)
+    rows = rng.integers(0, m, ns).astype(np.int64)
+    cols = rng.integers(0, n, ns).astype(np.int64)
+    return float(L.oz_oracle_relative_residual_sampled_z(op_code(op_a), op_code(op_b), m, n, k, _p(a), _zld(a), _p(b),
+                                                         _zld(b), _p(c), _zld(c), ns, _p(rows), _p(cols)))

@@ -215,6 +215,47 @@ static double accumulate_scale(int L, int a_id, int b_id) {
   return u2d((uint64_t)(0x3FF - rshift) << 52);
 }
 
+/* the pair loop of src/gemm.cu:385-403 (OZ_ORDER_REFERENCE) or its diagonal-grouped form: fills acc[m*n]
+ * (column-major, ld = m) from K-contiguous planes [S][rows][ldo].  Returns 0, 2 on allocation failure. */
+static int accumulate_products(const int8_t *ap, const int8_t *bp, size_t m, size_t n, size_t ldo, int S, int L,
+                               int order, size_t kchunk, double *acc) {
+  const size_t pa = m * ldo, pb = n * ldo;
+  memset(acc, 0, sizeof(double) * m * n); /* :367 / :481 init_accumulator_buffer */
+  if (order == OZ_ORDER_REFERENCE) {
+    int32_t *c32 = (int32_t *)malloc(sizeof(int32_t) * m * n);
+    if (!c32) return 2;
+    int ai[200], bi[200];
+    const int P = oz_oracle_pair_list(S, ai, bi);
+    for (int p = 0; p < P; p++) { /* :385-403 */
+      oz_oracle_int8_gemm(ap + (size_t)(ai[p] - 1) * pa, bp + (size_t)(bi[p] - 1) * pb, m, n, ldo, c32);
+      const double scale = accumulate_scale(L, ai[p], bi[p]);
+#pragma omp parallel for schedule(static)
+      for (long long t = 0; t < (long long)(m * n); t++) /* :86-88 */
+        acc[t] += (double)((int64_t)c32[t] << 32) * scale;
+    }
+    free(c32);
+    return 0;
+  }
+  /* diagonal grouping: per K-chunk, D_t = sum_{i+j=t} A_i B_j^T exactly (integers), then
+   * acc = fma((double)D_t, 2^(46-L*t), acc), t ascending, chunks outer. */
+  if (kchunk == 0 || kchunk > ldo) kchunk = ldo ? ldo : 1;
+  int64_t *dsum = (int64_t *)malloc(sizeof(int64_t) * (size_t)S * m * n);
+  if (!dsum) return 2;
+  for (size_t k0 = 0; k0 < ldo; k0 += kchunk) {
+    const size_t k1 = k0 + kchunk < ldo ? k0 + kchunk : ldo;
+    oz_oracle_diagonal_sums(ap, bp, m, n, ldo, S, k0, k1, dsum);
+    for (int t = 2; t <= S + 1; t++) {
+      /* same power of two the reference applies to a pair on this diagonal: 2^32 * 2^-rshift */
+      const double sc = 4294967296.0 * accumulate_scale(L, 1, t - 1);
+      const int64_t *dt = dsum + (size_t)(t - 2) * m * n;
+#pragma omp parallel for schedule(static)
+      for (long long e = 0; e < (long long)(m * n); e++) acc[e] = fma((double)dt[e], sc, acc[e]);
+    }
+  }
+  free(dsum);
+  return 0;
+}
+
 int oz_oracle_gemm(int op_a, int op_b, size_t m, size_t n, size_t k, double alpha, const double *a,
                    size_t lda, const double *b, size_t ldb, double beta, double *c, size_t ldc, int S,
                    int order, size_t kchunk, int quirks) {
@@ -230,48 +271,17 @@ int oz_oracle_gemm(int op_a, int op_b, size_t m, size_t n, size_t k, double alph
   int8_t *bp = (int8_t *)malloc((size_t)S * n * (ldo ? ldo : 1));
   double *ea = (double *)malloc(sizeof(double) * m);
   double *eb = (double *)malloc(sizeof(double) * n);
-  double *acc = (double *)calloc(m * n, sizeof(double)); /* :367 init_accumulator_buffer */
-  int32_t *c32 = (int32_t *)malloc(sizeof(int32_t) * m * n);
-  if (!ap || !bp || !ea || !eb || !acc || !c32) {
-    free(ap), free(bp), free(ea), free(eb), free(acc), free(c32);
+  double *acc = (double *)malloc(sizeof(double) * m * n);
+  if (!ap || !bp || !ea || !eb || !acc) {
+    free(ap), free(bp), free(ea), free(eb), free(acc);
     return 2;
   }
 
   oz_oracle_split_A(op_a, m, k, a, lda, S, L, ap, ldo, ea, quirks); /* :381-383 */
   oz_oracle_split_B(op_b, k, n, b, ldb, S, L, bp, ldo, eb, quirks);
-
-  const size_t pa = m * ldo, pb = n * ldo;
-  if (order == OZ_ORDER_REFERENCE) {
-    int ai[200], bi[200];
-    const int P = oz_oracle_pair_list(S, ai, bi);
-    for (int p = 0; p < P; p++) { /* :385-403 */
-      oz_oracle_int8_gemm(ap + (size_t)(ai[p] - 1) * pa, bp + (size_t)(bi[p] - 1) * pb, m, n, ldo, c32);
-      const double scale = accumulate_scale(L, ai[p], bi[p]);
-#pragma omp parallel for schedule(static)
-      for (long long t = 0; t < (long long)(m * n); t++) /* :86-88 */
-        acc[t] += (double)((int64_t)c32[t] << 32) * scale;
-    }
-  } else {
-    /* diagonal grouping: per K-chunk, D_t = sum_{i+j=t} A_i B_j^T exactly (integers), then
-     * acc = fma((double)D_t, 2^(46-L*t), acc), t ascending, chunks outer. */
-    if (kchunk == 0 || kchunk > ldo) kchunk = ldo ? ldo : 1;
-    int64_t *dsum = (int64_t *)malloc(sizeof(int64_t) * (size_t)S * m * n);
-    if (!dsum) {
-      free(ap), free(bp), free(ea), free(eb), free(acc), free(c32);
-      return 2;
-    }
-    for (size_t k0 = 0; k0 < ldo; k0 += kchunk) {
-      const size_t k1 = k0 + kchunk < ldo ? k0 + kchunk : ldo;
-      oz_oracle_diagonal_sums(ap, bp, m, n, ldo, S, k0, k1, dsum);
-      for (int t = 2; t <= S + 1; t++) {
-        /* same power of two the reference applies to a pair on this diagonal: 2^32 * 2^-rshift */
-        const double sc = 4294967296.0 * accumulate_scale(L, 1, t - 1);
-        const int64_t *dt = dsum + (size_t)(t - 2) * m * n;
-#pragma omp parallel for schedule(static)
-        for (long long e = 0; e < (long long)(m * n); e++) acc[e] = fma((double)dt[e], sc, acc[e]);
-      }
-    }
-    free(dsum);
+  if (accumulate_products(ap, bp, m, n, ldo, S, L, order, kchunk, acc)) {
+    free(ap), free(bp), free(ea), free(eb), free(acc);
+    return 2;
   }
 
   /* src/gemm.cu:124-148 axby_kernel */
@@ -286,8 +296,83 @@ int oz_oracle_gemm(int op_a, int op_b, size_t m, size_t n, size_t k, double alph
         *y = alpha * x;
     }
   }
-  free(ap), free(bp), free(ea), free(eb), free(acc), free(c32);
+  free(ap), free(bp), free(ea), free(eb), free(acc);
   return 0;
+}
+
+/*
+ * src/gemm.cu:412-521 gemm_int8<cuDoubleComplex>; complex branches of the split: src/split.cu:69-152, :211-240;
+ * init_c_complex :199-239 (with its read-after-write bug at :218-219 fixed: both components use the original c);
+ * axy_complex :160-186.  Operands are interleaved (re, im) doubles; alpha, beta: {re, im}.
+ */
+int oz_oracle_zgemm(int op_a, int op_b, size_t m, size_t n, size_t k, const double alpha[2], const double *a,
+                    size_t lda, const double *b, size_t ldb, const double beta[2], double *c, size_t ldc, int S,
+                    int order, size_t kchunk, int quirks) {
+  if (bad_shape(op_a, m, k, lda) || bad_shape(op_b, k, n, ldb) || bad_shape(OZ_OP_N, m, n, ldc)) return 1;
+  if (S < 3 || S > 18) return 1;
+  if (m == 0 || n == 0) return 0;
+  const int L = (int)oz_oracle_bits_per_int8((uint32_t)k); /* :425 */
+  const size_t ldo = oz_oracle_pad4(k);
+  const size_t pl = ldo ? ldo : 1;
+  int8_t *ap[2], *bp[2];
+  double *ea[2], *eb[2];
+  for (int q = 0; q < 2; q++) {
+    ap[q] = (int8_t *)malloc((size_t)S * m * pl);
+    bp[q] = (int8_t *)malloc((size_t)S * n * pl);
+    ea[q] = (double *)malloc(sizeof(double) * m);
+    eb[q] = (double *)malloc(sizeof(double) * n);
+  }
+  double *acc = (double *)malloc(sizeof(double) * m * n);
+  /* split Re and Im separately, each with its own row maxima (src/split.cu:69-152, :211-216) */
+  for (int q = 0; q < 2; q++) {
+    if (op_a == OZ_OP_N)
+      oz_oracle_split(a + q, m, k, 2, 2 * lda, S, L, ap[q], ldo, ea[q], quirks);
+    else
+      oz_oracle_split(a + q, m, k, 2 * lda, 2, S, L, ap[q], ldo, ea[q], quirks);
+    if (op_b == OZ_OP_N)
+      oz_oracle_split(b + q, n, k, 2 * ldb, 2, S, L, bp[q], ldo, eb[q], quirks);
+    else
+      oz_oracle_split(b + q, n, k, 2, 2 * ldb, S, L, bp[q], ldo, eb[q], quirks);
+  }
+  /* :477 init_c_complex */
+  const int beta_zero = beta[0] == 0 && beta[1] == 0; /* :230 */
+#pragma omp parallel for schedule(static)
+  for (long long j = 0; j < (long long)n; j++)
+    for (size_t i = 0; i < m; i++) {
+      double *y = c + 2 * ((size_t)j * ldc + i);
+      if (beta_zero) {
+        y[0] = 0, y[1] = 0;
+      } else {
+        const double cx = y[0], cy = y[1];
+        y[0] = fma(cx, beta[0], -(cy * beta[1]));
+        y[1] = fma(cy, beta[0], cx * beta[1]);
+      }
+    }
+  static const int order4[4][2] = {{1, 1}, {0, 0}, {1, 0}, {0, 1}}; /* :479-480 */
+  int rc = 0;
+  for (int t = 0; t < 4 && !rc; t++) {
+    const int pa = order4[t][0], pb = order4[t][1];
+    rc = accumulate_products(ap[pa], bp[pb], m, n, ldo, S, L, order, kchunk, acc);
+    double ar, ai; /* :501-512 */
+    if (pa == 0 && pb == 0) {
+      ar = alpha[0], ai = alpha[1];
+    } else if (pa == 1 && pb == 1) {
+      ar = -alpha[0], ai = -alpha[1];
+    } else {
+      ar = -alpha[1], ai = alpha[0];
+    }
+#pragma omp parallel for schedule(static)
+    for (long long j = 0; j < (long long)n; j++)
+      for (size_t i = 0; i < m; i++) { /* axy_complex_kernel :177-185, `a*x + y` contracted to fma */
+        const double x = acc[(size_t)j * m + i] / (double)(1ll << 44) * ea[pa][i] * eb[pb][j];
+        double *y = c + 2 * ((size_t)j * ldc + i);
+        y[0] = fma(ar, x, y[0]);
+        y[1] = fma(ai, x, y[1]);
+      }
+  }
+  for (int q = 0; q < 2; q++) free(ap[q]), free(bp[q]), free(ea[q]), free(eb[q]);
+  free(acc);
+  return rc;
 }
 
 /* src/split.cu:317-350 (per element) + :352-380 (per row) */
@@ -422,6 +507,60 @@ double oz_oracle_relative_residual_sampled(int op_a, int op_b, size_t m, size_t 
       const long double d = (long double)c[j * ldc + i] - acc;
       lnum += d * d;
       lden += acc * acc;
+    }
+#pragma omp critical
+    {
+      num += lnum;
+      den += lden;
+    }
+  }
+  return (double)sqrtl(num / den);
+}
+
+/* src/split.cu:454-494 with cuDoubleComplex (:367-374: Re and Im both counted; denominator m*k + k*n) */
+int oz_oracle_auto_select_z(int op_a, int op_b, size_t m, size_t n, size_t k, const double *a, size_t lda,
+                            const double *b, size_t ldb, double threshold, uint64_t counters_out[16]) {
+  const int L = (int)oz_oracle_bits_per_int8((uint32_t)k);
+  uint64_t cnt[16] = {0};
+  for (int q = 0; q < 2; q++) {
+    if (op_a == OZ_OP_N)
+      oz_oracle_mantissa_loss(a + q, m, k, 2, 2 * lda, L, cnt);
+    else
+      oz_oracle_mantissa_loss(a + q, m, k, 2 * lda, 2, L, cnt);
+    if (op_b == OZ_OP_N)
+      oz_oracle_mantissa_loss(b + q, n, k, 2 * ldb, 2, L, cnt);
+    else
+      oz_oracle_mantissa_loss(b + q, n, k, 2, 2 * ldb, L, cnt);
+  }
+  if (counters_out) memcpy(counters_out, cnt, sizeof(cnt));
+  const double denom = (double)(m * k + k * n);
+  for (int s = 3; s <= 18; s++)
+    if ((double)cnt[s - 3] / denom <= threshold) return s;
+  return 0;
+}
+
+/* ||C - op(A)op(B)||_F / ||op(A)op(B)||_F for interleaved complex operands, on sampled entries */
+double oz_oracle_relative_residual_sampled_z(int op_a, int op_b, size_t m, size_t n, size_t k, const double *a,
+                                             size_t lda, const double *b, size_t ldb, const double *c, size_t ldc,
+                                             size_t ns, const int64_t *rows, const int64_t *cols) {
+  (void)m, (void)n;
+  long double num = 0, den = 0;
+#pragma omp parallel
+  {
+    long double lnum = 0, lden = 0;
+#pragma omp for schedule(static)
+    for (long long s = 0; s < (long long)ns; s++) {
+      const size_t i = (size_t)rows[s], j = (size_t)cols[s];
+      long double re = 0, im = 0;
+      for (size_t kk = 0; kk < k; kk++) {
+        const double *pa = a + 2 * (op_a == OZ_OP_N ? kk * lda + i : i * lda + kk);
+        const double *pb = b + 2 * (op_b == OZ_OP_N ? j * ldb + kk : kk * ldb + j);
+        re += (long double)pa[0] * pb[0] - (long double)pa[1] * pb[1];
+        im += (long double)pa[0] * pb[1] + (long double)pa[1] * pb[0];
+      }
+      const long double dr = (long double)c[2 * (j * ldc + i)] - re, di = (long double)c[2 * (j * ldc + i) + 1] - im;
+      lnum += dr * dr + di * di;
+      lden += re * re + im * im;
     }
 #pragma omp critical
     {

@@ -91,6 +91,17 @@ int oz_oracle_gemm(int op_a, int op_b, size_t m, size_t n, size_t k, double alph
                    size_t lda, const double *b, size_t ldb, double beta, double *c, size_t ldc, int S,
                    int order, size_t kchunk, int quirks);
 
+/* src/gemm.cu:412-521 (gemm_int8<cuDoubleComplex>), :160-239; complex split src/split.cu:69-152, :211-240.
+ * Interleaved (re, im) operands; alpha/beta = {re, im}.  Same order / kchunk / quirks as oz_oracle_gemm. */
+int oz_oracle_zgemm(int op_a, int op_b, size_t m, size_t n, size_t k, const double alpha[2], const double *a,
+                    size_t lda, const double *b, size_t ldb, const double beta[2], double *c, size_t ldc, int S,
+                    int order, size_t kchunk, int quirks);
+int oz_oracle_auto_select_z(int op_a, int op_b, size_t m, size_t n, size_t k, const double *a, size_t lda,
+                            const double *b, size_t ldb, double threshold, uint64_t counters_out[16]);
+double oz_oracle_relative_residual_sampled_z(int op_a, int op_b, size_t m, size_t n, size_t k, const double *a,
+                                             size_t lda, const double *b, size_t ldb, const double *c, size_t ldc,
+                                             size_t ns, const int64_t *rows, const int64_t *cols);
+
 /* src/split.cu:317-380: mantissa-loss totals for S=3..18 (16 counters, the intended length;
  * the reference allocates 8: src/handle.hpp:22).  counters are accumulated into (not zeroed). */
 void oz_oracle_mantissa_loss(const double *in, size_t rows, size_t K, size_t stride_r,

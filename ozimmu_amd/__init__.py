@@ -193,7 +193,11 @@ def gemm(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr
          element_kind=real):
     """mtk::ozimmu::gemm (include/ozimmu/ozimmu.hpp:75-82).  alpha/beta: Python floats (host scalars);
     a/b/c: column-major device buffers (torch tensors or raw pointers).  Returns the int status."""
-    al, be = C.c_double(alpha), C.c_double(beta)
+    if element_kind == complx:  # cuDoubleComplex scalars: {re, im}
+        al = (C.c_double * 2)(complex(alpha).real, complex(alpha).imag)
+        be = (C.c_double * 2)(complex(beta).real, complex(beta).imag)
+    else:
+        al, be = C.c_double(alpha), C.c_double(beta)
     return int(lib().ozimmu_hip_gemm(handle.ptr, _op(op_A), _op(op_B), m, n, k, C.addressof(al), _ptr(a_ptr), lda,
                                      _ptr(b_ptr), ldb, C.addressof(be), _ptr(c_ptr), ldc, _mode(compute_mode),
                                      element_kind))

@@ -208,6 +208,120 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   return 0;
 }
 
+// Re (part 0) or Im (part 1) of an interleaved complex operand, as a strided real view
+static OperandView view_A_part(ozimmu_operation_t op, size_t m, size_t k, const double *a, size_t lda, int part) {
+  return op == OZIMMU_OP_N ? OperandView{a + part, m, k, 2, 2 * lda} : OperandView{a + part, m, k, 2 * lda, 2};
+}
+static OperandView view_B_part(ozimmu_operation_t op, size_t k, size_t n, const double *b, size_t ldb, int part) {
+  return op == OZIMMU_OP_N ? OperandView{b + part, n, k, 2 * ldb, 2} : OperandView{b + part, n, k, 2, 2 * ldb};
+}
+
+struct WorkspaceZ {
+  uint32_t *exps_a[2], *exps_b[2], *phase;
+  double *ea[2], *eb[2];
+  int8_t *planes_a[2], *planes_b[2];
+  double *acc;
+  size_t exps_bytes, total;
+};
+
+static WorkspaceZ carve_z(void *base, size_t m, size_t n, size_t k, int S, bool need_acc) {
+  WorkspaceZ w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void *p = base ? (void *)((char *)base + off) : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  for (int i = 0; i < 2; i++) w.exps_a[i] = (uint32_t *)take(4 * m);
+  for (int i = 0; i < 2; i++) w.exps_b[i] = (uint32_t *)take(4 * n);
+  w.phase = (uint32_t *)take(8 * 256);
+  w.exps_bytes = off;
+  for (int i = 0; i < 2; i++) w.ea[i] = (double *)take(8 * m);
+  for (int i = 0; i < 2; i++) w.eb[i] = (double *)take(8 * n);
+  for (int i = 0; i < 2; i++) w.planes_a[i] = (int8_t *)take(tiled_plane_bytes(m, k, S));
+  for (int i = 0; i < 2; i++) w.planes_b[i] = (int8_t *)take(tiled_plane_bytes(n, k, S));
+  w.acc = need_acc ? (double *)take(8 * m * n) : nullptr;
+  w.total = off;
+  return w;
+}
+
+// gemm_int8<cuDoubleComplex> (src/gemm.cu:412-521): Re and Im are split separately (own row exponents), C is
+// scaled by beta first, then four real Ozaki products (Im,Im), (Re,Re), (Im,Re), (Re,Im) are added with the
+// factors -alpha, alpha, i*alpha, i*alpha -- in that order (:479-518).  Each product runs the same fused kernel
+// as the real path; its epilogue adds the scaled product into the complex C.
+static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                             size_t n, size_t k, const double *alpha, const double *a, size_t lda, const double *b,
+                             size_t ldb, const double *beta, double *c, size_t ldc, int S) {
+  const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k);
+  const size_t kc = max_k_per_pass(S, L);
+  const bool acc_needed = needs_acc(k, S);
+  WorkspaceZ sz = carve_z(nullptr, m, n, k, S, acc_needed);
+  if (!ensure_workspace(h, sz.total)) return 3;
+  WorkspaceZ w = carve_z(h->working_memory_ptr, m, n, k, S, acc_needed);
+
+  const bool prof = h->profiling;
+  if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
+  if (!hip_ok(hipMemsetAsync(w.exps_a[0], 0, w.exps_bytes, h->stream), "memset")) return 3;
+  for (int part = 0; part < 2; part++)
+    if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), w.exps_a[part], S, L, w.planes_a[part], w.ea[part]))
+      return 3;
+  if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+  for (int part = 0; part < 2; part++)
+    if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), w.exps_b[part], S, L, w.planes_b[part], w.eb[part]))
+      return 3;
+  if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
+
+  if (!hip_ok(launch_scale_c_complex(m, n, c, ldc, beta[0], beta[1], h->stream), "scale_c")) return 3; // :477
+
+  static const int order[4][2] = {{1, 1}, {0, 0}, {1, 0}, {0, 1}}; // src/gemm.cu:479-480
+  for (const auto &pq : order) {
+    SliceGemmArgs g{};
+    g.a_planes = w.planes_a[pq[0]];
+    g.b_planes = w.planes_b[pq[1]];
+    g.KB = (uint32_t)k_blocks(k);
+    g.M = (uint32_t)m;
+    g.N = (uint32_t)n;
+    g.L = L;
+    g.ea = w.ea[pq[0]];
+    g.eb = w.eb[pq[1]];
+    g.cplx = 1;
+    if (pq[0] == 0 && pq[1] == 0) { // src/gemm.cu:501-512
+      g.alpha = alpha[0];
+      g.alpha_im = alpha[1];
+    } else if (pq[0] == 1 && pq[1] == 1) {
+      g.alpha = -alpha[0];
+      g.alpha_im = -alpha[1];
+    } else {
+      g.alpha = -alpha[1];
+      g.alpha_im = alpha[0];
+    }
+    g.c = c;
+    g.ldc = ldc;
+    g.acc = w.acc;
+    g.phase = env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) ? nullptr : w.phase;
+    const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
+    for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
+      g.kb0 = kb0;
+      g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
+      g.acc_in = kb0 != 0;
+      g.final = g.kb1 == g.KB;
+      if (!hip_ok(launch_slice_gemm(S, g, h->stream), "slice_gemm")) return 3;
+    }
+  }
+  if (prof) {
+    if (!hip_ok(hipEventRecord(h->ev[3], h->stream), "event")) return 3;
+    if (!hip_ok(hipEventSynchronize(h->ev[3]), "event sync")) return 3;
+    for (int i = 0; i < 3; i++) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]);
+      h->stage_last_ms[i] = ms;
+      h->stage_total_ms[i] += ms;
+    }
+    h->stage_calls++;
+  }
+  return 0;
+}
+
 } // namespace ozhip
 
 // ---- C ABI ---------------------------------------------------------------------------------------------
@@ -360,7 +474,8 @@ size_t ozimmu_hip_working_memory_size(ozimmu_operation_t, ozimmu_operation_t, si
                                       ozimmu_element_kind_t element_kind, ozimmu_compute_mode_t mode) {
   int S = num_split_of_mode(mode);
   if (mode == OZIMMU_FP64_INT8_AUTO) S = 18; // worst case of what auto may select
-  if (S == 0 || element_kind != OZIMMU_REAL) return 0;
+  if (S == 0) return 0;
+  if (element_kind != OZIMMU_REAL) return carve_z(nullptr, m, n, k, S, needs_acc(k, S)).total;
   return carve(nullptr, m, n, k, S, needs_acc(k, S)).total;
 }
 
@@ -393,29 +508,60 @@ int ozimmu_hip_native_dgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozim
                     (rocblas_int)ldb, beta, c, (rocblas_int)ldc);
 }
 
-int ozimmu_hip_mantissa_loss(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
-                             size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb,
-                             uint64_t counters[16]) {
-  if (!h || !counters) return 1;
+// native complex GEMM for the `dgemm` mode with complex operands (src/gemm.cu:639-645 with CUDA_C_64F)
+static int native_zgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m, size_t n,
+                        size_t k, const void *alpha, const void *a, size_t lda, const void *b, size_t ldb,
+                        const void *beta, void *c, size_t ldc) {
+  typedef rocblas_status (*create_t)(rocblas_handle *);
+  typedef rocblas_status (*set_stream_t)(rocblas_handle, hipStream_t);
+  typedef rocblas_status (*zgemm_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                    rocblas_int, const rocblas_double_complex *, const rocblas_double_complex *,
+                                    rocblas_int, const rocblas_double_complex *, rocblas_int,
+                                    const rocblas_double_complex *, rocblas_double_complex *, rocblas_int);
+  static create_t create = (create_t)vendor_symbol("rocblas_create_handle");
+  static set_stream_t set_stream = (set_stream_t)vendor_symbol("rocblas_set_stream");
+  static zgemm_t zgemm = (zgemm_t)vendor_symbol("rocblas_zgemm");
+  if (!create || !set_stream || !zgemm) return (int)rocblas_status_internal_error;
+  if (!h->rocblas_handle) {
+    rocblas_handle rh = nullptr;
+    const rocblas_status st = create(&rh);
+    if (st != rocblas_status_success) return (int)st;
+    h->rocblas_handle = rh;
+  }
+  set_stream((rocblas_handle)h->rocblas_handle, h->stream);
+  return (int)zgemm((rocblas_handle)h->rocblas_handle, to_rocblas_op(op_A), to_rocblas_op(op_B), (rocblas_int)m,
+                    (rocblas_int)n, (rocblas_int)k, (const rocblas_double_complex *)alpha,
+                    (const rocblas_double_complex *)a, (rocblas_int)lda, (const rocblas_double_complex *)b,
+                    (rocblas_int)ldb, (const rocblas_double_complex *)beta, (rocblas_double_complex *)c,
+                    (rocblas_int)ldc);
+}
+
+// real: a/b are double arrays; complex (src/split.cu:367-374): Re and Im counted separately, same 16 counters
+static int mantissa_loss_impl(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                              size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb, bool cplx,
+                              uint64_t counters[16]) {
   std::lock_guard<std::mutex> lock(h->mtx);
   const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/split.cu:461
-  const size_t exps_bytes = align256(4 * m) + align256(4 * n);
+  const int parts = cplx ? 2 : 1;
+  const size_t ea = align256(4 * m), eb = align256(4 * n), exps_bytes = parts * (ea + eb);
   if (!ensure_workspace(h, exps_bytes)) return 3;
-  uint32_t *exps_a = (uint32_t *)h->working_memory_ptr;
-  uint32_t *exps_b = (uint32_t *)((char *)h->working_memory_ptr + align256(4 * m));
-  const OperandView va = view_A(op_A, m, k, a, lda), vb = view_B(op_B, k, n, b, ldb);
-  bool ok = hip_ok(hipMemsetAsync(exps_a, 0, exps_bytes, h->stream), "memset") &&
+  char *base = (char *)h->working_memory_ptr;
+  bool ok = hip_ok(hipMemsetAsync(base, 0, exps_bytes, h->stream), "memset") &&
             hip_ok(hipMemsetAsync(h->d_mantissa_loss_counter_ptr, 0, 16 * sizeof(unsigned long long), h->stream),
-                   "memset") && // all 16 zeroed (src/split.cu:302-315 zeroes 8)
-            hip_ok(launch_row_max_exp(va, exps_a, h->stream), "row_max_exp") &&
-            hip_ok(launch_row_max_exp(vb, exps_b, h->stream), "row_max_exp") &&
-            hip_ok(launch_mantissa_loss(va, exps_a, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss") &&
-            hip_ok(launch_mantissa_loss(vb, exps_b, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss");
+                   "memset"); // all 16 zeroed (src/split.cu:302-315 zeroes 8)
+  for (int part = 0; part < parts && ok; part++) {
+    uint32_t *xa = (uint32_t *)(base + part * (ea + eb)), *xb = (uint32_t *)(base + part * (ea + eb) + ea);
+    const OperandView va = cplx ? view_A_part(op_A, m, k, a, lda, part) : view_A(op_A, m, k, a, lda);
+    const OperandView vb = cplx ? view_B_part(op_B, k, n, b, ldb, part) : view_B(op_B, k, n, b, ldb);
+    ok = hip_ok(launch_row_max_exp(va, xa, h->stream), "row_max_exp") &&
+         hip_ok(launch_row_max_exp(vb, xb, h->stream), "row_max_exp") &&
+         hip_ok(launch_mantissa_loss(va, xa, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss") &&
+         hip_ok(launch_mantissa_loss(vb, xb, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss");
+  }
   if (!ok) return 3;
   unsigned long long host[16];
   // blocking download, as src/split.cu:404-408
-  if (!hip_ok(hipMemcpyAsync(host, h->d_mantissa_loss_counter_ptr, sizeof(host), hipMemcpyDeviceToHost,
-                             h->stream),
+  if (!hip_ok(hipMemcpyAsync(host, h->d_mantissa_loss_counter_ptr, sizeof(host), hipMemcpyDeviceToHost, h->stream),
               "memcpy") ||
       !hip_ok(hipStreamSynchronize(h->stream), "sync"))
     return 3;
@@ -423,13 +569,21 @@ int ozimmu_hip_mantissa_loss(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   return 0;
 }
 
+int ozimmu_hip_mantissa_loss(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                             size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb,
+                             uint64_t counters[16]) {
+  if (!h || !counters) return 1;
+  return mantissa_loss_impl(h, op_A, op_B, m, n, k, a, lda, b, ldb, false, counters);
+}
+
 ozimmu_compute_mode_t ozimmu_hip_auto_mode_select(ozimmu_hip_handle_t h, ozimmu_operation_t op_A,
                                                   ozimmu_operation_t op_B, size_t m, size_t n, size_t k,
                                                   const void *a, size_t lda, const void *b, size_t ldb,
                                                   ozimmu_element_kind_t element_kind, double threshold) {
-  if (!h || element_kind != OZIMMU_REAL) return OZIMMU_DGEMM;
+  if (!h) return OZIMMU_DGEMM;
   uint64_t cnt[16];
-  if (ozimmu_hip_mantissa_loss(h, op_A, op_B, m, n, k, (const double *)a, lda, (const double *)b, ldb, cnt))
+  if (mantissa_loss_impl(h, op_A, op_B, m, n, k, (const double *)a, lda, (const double *)b, ldb,
+                         element_kind != OZIMMU_REAL, cnt))
     return OZIMMU_DGEMM;
   const double denom = (double)(m * k + k * n); // src/split.cu:486
   for (int s = 3; s <= 18; s++)
@@ -456,11 +610,8 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
     log_error("Not implemented (unknown compute mode)"); // OZIMMU_NOT_IMPLEMENTED throws in the reference
     return 2;
   }
-  if (element_kind != OZIMMU_REAL) {
-    log_error("complex (ZGEMM) Ozaki path is not implemented in this build");
-    return 2;
-  }
   if (m == 0 || n == 0) return 0;
+  const bool cplx = element_kind != OZIMMU_REAL;
 
   if (mode == OZIMMU_FP64_INT8_AUTO) { // src/gemm.cu:628-638
     const ozimmu_compute_mode_t auto_mode = ozimmu_hip_auto_mode_select(
@@ -470,13 +621,17 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
     return ozimmu_hip_gemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, auto_mode, element_kind);
   }
   const int S = num_split_of_mode(mode);
-  if (S == 0 || k == 0) {
+  if (S == 0 || (k == 0 && !cplx)) {
     // `dgemm` (src/gemm.cu:639-645); `sgemm` (FP32 emulation, out of scope) and k == 0 also go native
-    const int st = ozimmu_hip_native_dgemm(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a,
-                                           lda, (const double *)b, ldb, (const double *)beta, (double *)c, ldc);
+    const int st = cplx ? native_zgemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc)
+                        : ozimmu_hip_native_dgemm(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a,
+                                                  lda, (const double *)b, ldb, (const double *)beta, (double *)c, ldc);
     return st == 0 ? 0 : 3;
   }
   std::lock_guard<std::mutex> lock(h->mtx);
+  if (cplx)
+    return gemm_int8_complex(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a, lda, (const double *)b,
+                             ldb, (const double *)beta, (double *)c, ldc, S);
   return gemm_int8_real(h, op_A, op_B, m, n, k, *(const double *)alpha, (const double *)a, lda,
                         (const double *)b, ldb, *(const double *)beta, (double *)c, ldc, S, nullptr);
 }

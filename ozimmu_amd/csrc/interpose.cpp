@@ -5,6 +5,7 @@
 //   cublasGemmEx                         (:133-278)  -> rocblas_gemm_ex, hipblasGemmEx (all-FP64 real case)
 //   cublasDgemm_v2                       (:280-295)  -> rocblas_dgemm, rocblas_dgemm_64, hipblasDgemm
 //   cublasDgemmStridedBatched            (:474-492)  -> rocblas_dgemm_strided_batched (sequential loop, :380-406)
+//   cublasZgemm_v2                       (:297-313)  -> rocblas_zgemm (and the f64_c case of rocblas_gemm_ex)
 // Originals are found with dlsym(RTLD_NEXT) (src/utils.hpp:117-141).
 //
 // Documented deviations from the reference (SURVEY.md §8a "quirks"):
@@ -84,8 +85,8 @@ const char *op_str(ozimmu_operation_t op) { return op == OZIMMU_OP_N ? "N" : "T"
 
 // The intercept predicate + the Ozaki path.  true = handled (C holds the result).
 bool try_ozaki(hipStream_t stream, bool host_pointer_mode, ozimmu_operation_t op_a, ozimmu_operation_t op_b,
-               long long m, long long n, long long k, const double *alpha, const double *A, long long lda,
-               const double *B, long long ldb, const double *beta, double *C, long long ldc) {
+               long long m, long long n, long long k, const void *alpha, const void *A, long long lda,
+               const void *B, long long ldb, const void *beta, void *C, long long ldc, bool cplx = false) {
   if (t_depth > 0) return false;
   const ozimmu_compute_mode_t mode = get_compute_mode();
   if (mode == OZIMMU_DGEMM || mode == OZIMMU_SGEMM) return false; // sgemm emulation: out of scope -> native
@@ -108,7 +109,7 @@ bool try_ozaki(hipStream_t stream, bool host_pointer_mode, ozimmu_operation_t op
   {
     DepthGuard guard; // auto mode may fall back to the vendor DGEMM underneath
     err = ozimmu_hip_gemm(h, op_a, op_b, (size_t)m, (size_t)n, (size_t)k, alpha, A, (size_t)lda, B, (size_t)ldb,
-                          beta, C, (size_t)ldc, mode, OZIMMU_REAL);
+                          beta, C, (size_t)ldc, mode, cplx ? OZIMMU_COMPLX : OZIMMU_REAL);
   }
   if (prof) {
     hipStreamSynchronize(stream);
@@ -116,7 +117,8 @@ bool try_ozaki(hipStream_t stream, bool host_pointer_mode, ozimmu_operation_t op
     const unsigned long ns =
         ((long)t1.tv_sec - (long)t0.tv_sec) * 1000000000l + ((long)t1.tv_nsec - (long)t0.tv_nsec);
     // src/cublas.cu:157-162 name format
-    std::printf("[CULiP Result][D%s-%s%s-m%lld-n%lld-k%lld] %luns\n", ozimmu_hip_get_compute_mode_name_str(mode),
+    std::printf("[CULiP Result][%s%s-%s%s-m%lld-n%lld-k%lld] %luns\n", cplx ? "Z" : "D",
+                ozimmu_hip_get_compute_mode_name_str(mode),
                 op_str(op_a), op_str(op_b), m, n, k, ns);
     std::fflush(stdout);
   }
@@ -251,9 +253,13 @@ rocblas_status rocblas_gemm_ex(rocblas_handle handle, rocblas_operation transA, 
   const bool f64 = a_type == rocblas_datatype_f64_r && b_type == rocblas_datatype_f64_r &&
                    c_type == rocblas_datatype_f64_r && d_type == rocblas_datatype_f64_r &&
                    compute_type == rocblas_datatype_f64_r && c == d && ldc == ldd;
-  if (t_depth == 0 && f64 && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, (const double *)alpha, (const double *)a,
-                lda, (const double *)b, ldb, (const double *)beta, (double *)d, ldd))
+  // ... or all FP64 complex (CUDA_C_64F, src/cublas.cu:147-148), without conjugation
+  const bool c64 = a_type == rocblas_datatype_f64_c && b_type == rocblas_datatype_f64_c &&
+                   c_type == rocblas_datatype_f64_c && d_type == rocblas_datatype_f64_c &&
+                   compute_type == rocblas_datatype_f64_c && c == d && ldc == ldd &&
+                   transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
+  if (t_depth == 0 && (f64 || c64) && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, a, lda, b, ldb, beta, d, ldd, c64))
     return rocblas_status_success;
   if (!fn) return rocblas_status_internal_error;
   DepthGuard guard;
@@ -302,6 +308,29 @@ rocblas_status rocblas_dgemm_strided_batched(rocblas_handle handle, rocblas_oper
   DepthGuard guard;
   return fn(handle, transA, transB, m, n, k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c,
             batch_count);
+}
+
+// cublasZgemm_v2 (src/cublas.cu:297-313).  Conjugate-transpose is passed through: the reference maps every non-N
+// operation to a plain transpose (src/cublas.cu:50-56), which is wrong for complex data.
+rocblas_status rocblas_zgemm(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB, rocblas_int m,
+                             rocblas_int n, rocblas_int k, const rocblas_double_complex *alpha,
+                             const rocblas_double_complex *A, rocblas_int lda, const rocblas_double_complex *B,
+                             rocblas_int ldb, const rocblas_double_complex *beta, rocblas_double_complex *C,
+                             rocblas_int ldc) {
+  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                 rocblas_int, const rocblas_double_complex *, const rocblas_double_complex *,
+                                 rocblas_int, const rocblas_double_complex *, rocblas_int,
+                                 const rocblas_double_complex *, rocblas_double_complex *, rocblas_int);
+  static fn_t fn = original<fn_t>("rocblas_zgemm");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  const bool no_conj = transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
+  if (t_depth == 0 && no_conj && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, true))
+    return rocblas_status_success;
+  if (!fn) return rocblas_status_internal_error;
+  DepthGuard guard;
+  return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
 // ---- hipBLAS (only reached when an application binds hipBLAS statically or resolves these first) --------

@@ -22,6 +22,8 @@ struct SliceGemmArgs {
   double alpha, beta;
   double *c;
   size_t ldc;
+  int cplx;        // 1: c is complex (interleaved), this launch adds (alpha + i*alpha_im) * product to it
+  double alpha_im;
   double *acc; // [N][M] FP64 partial sums (multi-pass only)
   int acc_in;  // start the fma chain from acc instead of 0
   int final;   // 1: scale + alpha/beta -> C; 0: -> acc
@@ -34,7 +36,12 @@ struct SliceGemmArgs {
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);
 
-// element (r, k) of the operand view lives at in[r * stride_r + k * stride_k]; exactly one stride is 1
+// C(complex, m x n, ldc) *= beta  (beta == 0: C = 0 without reading it); init_c_complex, src/gemm.cu:199-239
+hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, double beta_re, double beta_im,
+                                  hipStream_t stream);
+
+// element (r, k) of the operand view lives at in[r * stride_r + k * stride_k] (strides in doubles); the smaller
+// stride is the contiguous axis: 1 for real operands, 2 for the Re or Im part of an interleaved complex operand
 struct OperandView {
   const double *in;
   size_t rows, K;

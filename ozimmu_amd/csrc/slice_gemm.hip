@@ -73,6 +73,28 @@ static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
   }
 }
 
+// init_c_complex_kernel (src/gemm.cu:199-223) without its read-after-write bug (:218-219 uses the updated c.x
+// for c.y): both components are computed from the ORIGINAL c.
+__global__ void scale_c_complex_kernel(size_t m, size_t n, double2 *c, size_t ldc, double br, double bi, int zero) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= m * n) return;
+  double2 *p = c + (tid / m) * ldc + tid % m;
+  if (zero) {
+    *p = make_double2(0.0, 0.0);
+  } else {
+    const double2 v = *p;
+    *p = make_double2(fma(v.x, br, -(v.y * bi)), fma(v.y, br, v.x * bi));
+  }
+}
+
+hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, double beta_re, double beta_im,
+                                  hipStream_t stream) {
+  if (m * n == 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_c_complex_kernel, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, stream, m, n,
+                     reinterpret_cast<double2 *>(c), ldc, beta_re, beta_im, (beta_re == 0.0 && beta_im == 0.0) ? 1 : 0);
+  return hipGetLastError();
+}
+
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream) {
   switch (S) {
 #define OZ_CASE(s) \

@@ -337,6 +337,16 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     } else {
       // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
       const double v = x * 0x1p-44 * ea * p.eb[n];
+      if (p.cplx) {
+        // one of the four real products of a ZGEMM: C += (alpha_re + i alpha_im) * v  (axy_complex_kernel,
+        // src/gemm.cu:160-186; C was scaled by beta beforehand, src/gemm.cu:199-239)
+        double2 *zp = reinterpret_cast<double2 *>(p.c) + ((size_t)n * p.ldc + m);
+        double2 y = *zp;
+        y.x = fma(p.alpha, v, y.x);
+        y.y = fma(p.alpha_im, v, y.y);
+        *zp = y;
+        continue;
+      }
       double *cp = p.c + (size_t)n * p.ldc + m;
       if (p.beta != 0.0)
         *cp = fma(p.alpha, v, p.beta * *cp);

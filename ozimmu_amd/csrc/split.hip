@@ -44,25 +44,25 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // ---- pass 1: per-row maximum exponent field ---------------------------------------------------------
 // k-contiguous operand: element (r,k) at in[r*ld + k].  One wave per row segment, lanes along k.
 __global__ __launch_bounds__(256) void row_max_kcontig_kernel(const double *__restrict__ in, size_t rows,
-                                                              size_t K, size_t ld, uint32_t *exps,
+                                                              size_t K, size_t sr, size_t sk, uint32_t *exps,
                                                               unsigned kchunk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t r = (size_t)blockIdx.x * 4 + wave;
   if (r >= rows) return;
   const size_t k0 = (size_t)blockIdx.y * kchunk;
   const size_t k1 = k0 + kchunk < K ? k0 + kchunk : K;
-  const double *p = in + r * ld;
+  const double *p = in + r * sr;
   unsigned e = 0;
   size_t k = k0 + lane;
   for (; k + 7 * 64 < k1; k += 8 * 64) {
     unsigned t[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) t[u] = exp_field(p[k + u * 64]);
+    for (int u = 0; u < 8; u++) t[u] = exp_field(p[(k + u * 64) * sk]);
 #pragma unroll
     for (int u = 0; u < 8; u++) e = t[u] > e ? t[u] : e;
   }
   for (; k < k1; k += 64) {
-    const unsigned t = exp_field(p[k]);
+    const unsigned t = exp_field(p[k * sk]);
     e = t > e ? t : e;
   }
   e = wave_max_u32(e);
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void row_max_kcontig_kernel(const double *__re
 
 // row-contiguous operand: element (r,k) at in[k*ld + r].  Lanes along r, the 4 waves interleave k.
 __global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__restrict__ in, size_t rows,
-                                                              size_t K, size_t ld, uint32_t *exps,
+                                                              size_t K, size_t sr, size_t sk, uint32_t *exps,
                                                               unsigned kchunk) {
   __shared__ unsigned red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,17 +80,17 @@ __global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__re
   const size_t k1 = k0 + kchunk < K ? k0 + kchunk : K;
   unsigned e = 0;
   if (r < rows) {
-    const double *p = in + r;
+    const double *p = in + r * sr;
     size_t k = k0 + wave;
     for (; k + 7 * 4 < k1; k += 8 * 4) {
       unsigned t[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) t[u] = exp_field(p[(k + u * 4) * ld]);
+      for (int u = 0; u < 8; u++) t[u] = exp_field(p[(k + u * 4) * sk]);
 #pragma unroll
       for (int u = 0; u < 8; u++) e = t[u] > e ? t[u] : e;
     }
     for (; k < k1; k += 4) {
-      const unsigned t = exp_field(p[k * ld]);
+      const unsigned t = exp_field(p[k * sk]);
       e = t > e ? t : e;
     }
   }
@@ -106,16 +106,16 @@ __global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__re
 
 hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream) {
   if (v.rows == 0 || v.K == 0) return hipSuccess;
-  if (v.stride_k == 1) {
+  if (v.stride_k < v.stride_r) {
     const unsigned kchunk = 8192;
     dim3 grid((unsigned)((v.rows + 3) / 4), (unsigned)((v.K + kchunk - 1) / kchunk));
     hipLaunchKernelGGL(row_max_kcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, exps, kchunk);
+                       v.stride_r, v.stride_k, exps, kchunk);
   } else {
     const unsigned kchunk = 512;
     dim3 grid((unsigned)((v.rows + 63) / 64), (unsigned)((v.K + kchunk - 1) / kchunk));
     hipLaunchKernelGGL(row_max_rcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_k, exps, kchunk);
+                       v.stride_r, v.stride_k, exps, kchunk);
   }
   return hipGetLastError();
 }
@@ -123,7 +123,7 @@ hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t 
 // ---- shared: load one 32 rows x 32 k block, lane (r = lane&31, kh = lane>>5) gets its 16 k values ---
 // Out-of-range rows / k read as +0.0 (-> zero slices: the padding the GEMM relies on).
 template <bool KCONTIG>
-__device__ __forceinline__ void load_block(const double *__restrict__ in, size_t rows, size_t K, size_t ld,
+__device__ __forceinline__ void load_block(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
                                            size_t rb, size_t kb, int lane, double (*tile)[33],
                                            double v[16]) {
   const int r = lane & 31, kh = lane >> 5;
@@ -133,7 +133,7 @@ __device__ __forceinline__ void load_block(const double *__restrict__ in, size_t
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const size_t k = kbase + q;
-      v[q] = (rg < rows && k < K) ? in[k * ld + rg] : 0.0;
+      v[q] = (rg < rows && k < K) ? in[k * sk + rg * sr] : 0.0;
     }
   } else {
     // coalesced read: half-wave = 32 consecutive k of one row; 2 rows per instruction
@@ -142,7 +142,7 @@ __device__ __forceinline__ void load_block(const double *__restrict__ in, size_t
     for (int it = 0; it < 16; it++) {
       const int rr = it * 2 + (lane >> 5);
       const size_t rg = rb * 32 + rr;
-      tile[rr][lane & 31] = (rg < rows && k < K) ? in[rg * ld + k] : 0.0;
+      tile[rr][lane & 31] = (rg < rows && k < K) ? in[rg * sr + k * sk] : 0.0;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -154,7 +154,7 @@ __device__ __forceinline__ void load_block(const double *__restrict__ in, size_t
 // ---- pass 2: cut ---------------------------------------------------------------------------------------
 template <bool KCONTIG>
 __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in, size_t rows, size_t K,
-                                                  size_t ld, const uint32_t *__restrict__ exps, int S, int L,
+                                                  size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
                                                   int8_t *__restrict__ planes, double *__restrict__ max_exp,
                                                   size_t RB, size_t KB) {
   __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
   const size_t kb = KCONTIG ? gw % KB : gw / RB;
 
   double v[16];
-  load_block<KCONTIG>(in, rows, K, ld, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
+  load_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
 
   const int r = lane & 31;
   const size_t rg = rb * 32 + r;
@@ -238,11 +238,11 @@ hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, 
   const size_t RB = row_blocks_padded(v.rows), KB = k_blocks(v.K);
   if (RB * KB == 0) return hipSuccess;
   const unsigned grid = (unsigned)((RB * KB + 3) / 4);
-  if (v.stride_k == 1)
-    hipLaunchKernelGGL(cut_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r,
+  if (v.stride_k < v.stride_r)
+    hipLaunchKernelGGL(cut_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
                        exps, S, L, planes, max_exp, RB, KB);
   else
-    hipLaunchKernelGGL(cut_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_k,
+    hipLaunchKernelGGL(cut_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
                        exps, S, L, planes, max_exp, RB, KB);
   return hipGetLastError();
 }
@@ -275,7 +275,7 @@ hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int
 // ---- auto mode: mantissa-loss statistic (src/split.cu:317-380) ---------------------------------------
 template <bool KCONTIG>
 __global__ __launch_bounds__(256) void mantissa_loss_kernel(const double *__restrict__ in, size_t rows,
-                                                            size_t K, size_t ld,
+                                                            size_t K, size_t sr, size_t sk,
                                                             const uint32_t *__restrict__ exps, int L,
                                                             unsigned long long *counters, size_t RB,
                                                             size_t KB) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void mantissa_loss_kernel(const double *__rest
     const size_t rb = KCONTIG ? gw / KB : gw % RB;
     const size_t kb = KCONTIG ? gw % KB : gw / RB;
     double v[16];
-    load_block<KCONTIG>(in, rows, K, ld, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
+    load_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
     const size_t rg = rb * 32 + (lane & 31);
     const unsigned e = rg < rows ? exps[rg] : 0u;
     if (e != 0u && e != 0x7FFu) { // max_exp != 0 (src/split.cu:322); non-finite rows carry no statistic
@@ -324,12 +324,12 @@ hipError_t launch_mantissa_loss(const OperandView &v, const uint32_t *exps, int 
   const size_t RB = (v.rows + 31) / 32, KB = k_blocks(v.K);
   if (RB * KB == 0) return hipSuccess;
   const unsigned grid = (unsigned)((RB * KB + 3) / 4);
-  if (v.stride_k == 1)
+  if (v.stride_k < v.stride_r)
     hipLaunchKernelGGL(mantissa_loss_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, exps, L, counters, RB, KB);
+                       v.stride_r, v.stride_k, exps, L, counters, RB, KB);
   else
     hipLaunchKernelGGL(mantissa_loss_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_k, exps, L, counters, RB, KB);
+                       v.stride_r, v.stride_k, exps, L, counters, RB, KB);
   return hipGetLastError();
 }
 

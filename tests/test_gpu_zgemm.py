@@ -1,0 +1,140 @@
+"""GPU parity tests of the complex path: gemm_int8<cuDoubleComplex>, src/gemm.cu:412-521 --
+Re/Im split separately, C scaled by beta, then four real Ozaki products (Im,Im) (Re,Re) (Im,Re) (Re,Im)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import ozimmu_amd
+from oracle import oracle as O
+from tests.util import ColMajor
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def zfill(kind):
+    def f(rng, shape):
+        if kind == "urand01":  # the reference's complex ci_test input: both parts uniform (0,1]
+            return (1.0 - rng.uniform(0, 1, shape)) + 1j * (1.0 - rng.uniform(0, 1, shape))
+        if kind == "wide":
+            return (rng.uniform(-1, 1, shape) * 10.0 ** (6 * rng.uniform(0, 1, shape))
+                    + 1j * rng.uniform(-1, 1, shape) * 10.0 ** (6 * rng.uniform(0, 1, shape)))
+        return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+    return f
+
+
+def zoperand(op, rows, cols, rng, kind="pm1", pad=0):
+    r, c = (rows, cols) if op == "N" else (cols, rows)
+    x = ColMajor(r, c, ld=r + pad, dtype=np.complex128)
+    x.buf[:, :r] = zfill(kind)(rng, (c, r))
+    if pad:
+        x.buf[:, r:] = np.nan
+    return x
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def zbits(x):
+    """bit patterns of a complex array: (2, ...) uint64"""
+    return np.stack([np.ascontiguousarray(x.real).view(np.uint64), np.ascontiguousarray(x.imag).view(np.uint64)])
+
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("m,n,k,S", [(64, 64, 64, 6), (1, 1, 1, 9), (70, 33, 129, 9), (130, 65, 257, 13)])
+def test_zgemm_bit_exact_vs_oracle(oz, op_a, op_b, m, n, k, S):
+    m_, h = oz
+    rng = np.random.default_rng(m + n + k + S)
+    a = zoperand(op_a, m, k, rng, "wide", pad=1)
+    b = zoperand(op_b, k, n, rng, "wide", pad=2)
+    c = zoperand("N", m, n, rng, pad=3)
+    c_ref = ColMajor(m, n, ld=m + 3, dtype=np.complex128)
+    c_ref.buf[...] = c.buf
+    alpha, beta = 1.25 - 0.5j, -0.75 + 2.0j
+    st = m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, f"fp64_int8_{S}", m_.complx)
+    _sync()
+    assert st == 0
+    assert O.zgemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    got = c.download()
+    np.testing.assert_array_equal(zbits(got), zbits(c_ref.view))
+    assert np.isnan(c.buf[:, m:]).all()                    # padding of C untouched
+
+
+def test_zgemm_beta_zero_does_not_read_c_and_real_alpha(oz):
+    m_, h = oz
+    m, n, k, S = 96, 80, 200, 9
+    rng = np.random.default_rng(1)
+    a = zoperand("N", m, k, rng)
+    b = zoperand("N", k, n, rng)
+    c = ColMajor(m, n, dtype=np.complex128)
+    c.buf[...] = np.nan
+    c_ref = ColMajor(m, n, dtype=np.complex128)
+    assert m_.gemm(h, "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, "fp64_int8_9", m_.complx) == 0
+    _sync()
+    O.zgemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL)
+    np.testing.assert_array_equal(zbits(c.download()), zbits(c_ref.view))
+    r = O.relative_residual_sampled_z("N", "N", m, n, k, a.view, b.view, c.view, ns=500)
+    assert r < 1e-15
+
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("S", [8, 12, 16])
+def test_reference_ci_gate_complex(oz, op_a, op_b, S):
+    """the complex half of test/main_test.cu:702-746: residual < 1e-15 for fp64_int8_8..16"""
+    m_, h = oz
+    m, n, k = 1023, 1025, 1024
+    rng = np.random.default_rng(0)
+    a = zoperand(op_a, m, k, rng, "urand01")
+    b = zoperand(op_b, k, n, rng, "urand01")
+    c = ColMajor(m, n, dtype=np.complex128)
+    assert m_.gemm(h, op_a, op_b, m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, f"fp64_int8_{S}",
+                   m_.complx) == 0
+    _sync()
+    r = O.relative_residual_sampled_z(op_a, op_b, m, n, k, a.view, b.view, c.download(), ns=2048)
+    assert r < 1e-15, r
+
+
+def test_zgemm_auto_mode(oz):
+    m_, h = oz
+    m, n, k = 100, 90, 260
+    rng = np.random.default_rng(3)
+    a = zoperand("T", m, k, rng, "wide")
+    b = zoperand("N", k, n, rng)
+    s_ref, _ = O.auto_select_z("T", "N", m, n, k, a.view, b.view, 1.5)
+    mode = m_.auto_mode_select(h, "T", "N", m, n, k, a.dev, a.ld, b.dev, b.ld, m_.complx, 1.5)
+    assert mode == (m_.dgemm if s_ref == 0 else m_.fp64_int8_3 + s_ref - 3)
+    # `dgemm` mode with complex operands goes to the vendor ZGEMM (src/gemm.cu:639-645)
+    c = ColMajor(m, n, dtype=np.complex128)
+    assert m_.gemm(h, "T", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, "dgemm", m_.complx) == 0
+    _sync()
+    assert O.relative_residual_sampled_z("T", "N", m, n, k, a.view, b.view, c.download(), ns=300) < 1e-14
+
+
+def test_pytorch_complex128_matmul_is_intercepted():
+    """torch.mm(complex128) -> hipblasZgemm -> rocblas_zgemm -> the shim (cublasZgemm_v2, src/cublas.cu:297-313)"""
+    code = textwrap.dedent("""
+        import torch
+        torch.manual_seed(0)
+        a = torch.rand(1100, 1024, dtype=torch.float64, device="cuda") + 1j * torch.rand(1100, 1024, dtype=torch.float64, device="cuda")
+        b = torch.rand(1024, 1050, dtype=torch.float64, device="cuda") - 1j * torch.rand(1024, 1050, dtype=torch.float64, device="cuda")
+        c = a @ b
+        torch.cuda.synchronize()
+        ref = a.cpu() @ b.cpu()
+        print("MAXDIFF %.3e" % ((c.cpu() - ref).abs().max() / ref.abs().max()).item())
+    """)
+    out = {}
+    for mode in ("fp64_int8_3", "fp64_int8_10"):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
+        e.update(LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE=mode, OZIMMU_ENABLE_CULIP_PROFILING="1")
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stdout + p.stderr
+        out[mode] = (float([l for l in p.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()[1]), p.stdout)
+    assert out["fp64_int8_3"][0] > 1e-7 and out["fp64_int8_10"][0] < 1e-13, (out["fp64_int8_3"][0], out["fp64_int8_10"][0])
+    assert "[CULiP Result][Zfp64_int8_10-" in out["fp64_int8_10"][1]

@@ -348,3 +348,59 @@ def test_oracle_reproduces_golden(path):
 
 def test_golden_fixtures_exist():
     assert len(GOLDEN) >= 4
+
+
+# ------------------------------------------------------------------ complex path (row F1)
+
+def _zrand(rng, r, c, kind="pm1"):
+    if kind == "urand01":
+        x = (1.0 - rng.uniform(0, 1, (r, c))) + 1j * (1.0 - rng.uniform(0, 1, (r, c)))
+    else:
+        x = rng.uniform(-1, 1, (r, c)) + 1j * rng.uniform(-1, 1, (r, c))
+    return np.asfortranarray(x)
+
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("order", [O.ORDER_REFERENCE, O.ORDER_DIAGONAL])
+def test_zgemm_matches_complex_matmul(op_a, op_b, order):
+    """gemm_int8<cuDoubleComplex> (src/gemm.cu:412-521): four real products with -alpha, alpha, i*alpha, i*alpha"""
+    rng = np.random.default_rng(2)
+    m, n, k, S = 45, 38, 77, 10
+    a = _zrand(rng, *((m, k) if op_a == "N" else (k, m)))
+    b = _zrand(rng, *((k, n) if op_b == "N" else (n, k)))
+    c0 = _zrand(rng, m, n)
+    alpha, beta = 0.5 + 1.5j, -1.25 + 0.25j
+    c = c0.copy(order="F")
+    assert O.zgemm(op_a, op_b, m, n, k, alpha, a, b, beta, c, S, order) == 0
+    ref = alpha * ((a if op_a == "N" else a.T) @ (b if op_b == "N" else b.T)) + beta * c0
+    assert np.abs(c - ref).max() <= 64 * 2.0 ** -52 * np.abs(ref).max()
+    # beta == 0: C is not read (init_c_complex_kernel<true>, src/gemm.cu:214-215)
+    c2 = np.full((m, n), np.nan + 0j, order="F")
+    assert O.zgemm(op_a, op_b, m, n, k, 1.0, a, b, 0.0, c2, S, order) == 0
+    assert np.isfinite(c2.real).all() and np.isfinite(c2.imag).all()
+    assert O.relative_residual_sampled_z(op_a, op_b, m, n, k, a, b, c2, ns=400) < 1e-15
+
+
+@pytest.mark.parametrize("S", [8, 11, 16])
+def test_reference_ci_gate_complex_on_cpu(S):
+    """the complex half of test/main_test.cu:702-746 (sizes reduced for the CPU suite)"""
+    rng = np.random.default_rng(S)
+    m, n, k = 255, 257, 256
+    for op_a in "NT":
+        for op_b in "NT":
+            a = _zrand(rng, *((m, k) if op_a == "N" else (k, m)), kind="urand01")
+            b = _zrand(rng, *((k, n) if op_b == "N" else (n, k)), kind="urand01")
+            c = np.zeros((m, n), dtype=np.complex128, order="F")
+            assert O.zgemm(op_a, op_b, m, n, k, 1.0, a, b, 0.0, c, S) == 0
+            assert O.relative_residual_sampled_z(op_a, op_b, m, n, k, a, b, c, ns=2000) < 1e-15
+
+
+def test_complex_auto_mode_counts_both_parts():
+    rng = np.random.default_rng(8)
+    m, n, k = 40, 30, 120
+    a, b = _zrand(rng, m, k), _zrand(rng, k, n)
+    s, cnt = O.auto_select_z("N", "N", m, n, k, a, b, 1.5)
+    _, cre = O.auto_select("N", "N", m, n, k, np.asfortranarray(a.real), np.asfortranarray(b.real), 1.5)
+    _, cim = O.auto_select("N", "N", m, n, k, np.asfortranarray(a.imag), np.asfortranarray(b.imag), 1.5)
+    np.testing.assert_array_equal(cnt, cre + cim)          # src/split.cu:367-374
+    assert s == next(S for S in range(3, 19) if cnt[S - 3] / (m * k + k * n) <= 1.5)

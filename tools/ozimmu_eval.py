@@ -44,7 +44,7 @@ def gen(kind, shape, gen_):
     raise SystemExit(f"unknown input mode {kind}")
 
 
-def eval_one(oz, O, h, kind, op_a, op_b, m, n, k, mode, reps, threshold=0.0, gpu_name="MI355X"):
+def eval_one(oz, O, h, kind, op_a, op_b, m, n, k, mode, reps, threshold=0.0, gpu_name="MI355X", cplx=False):
     import numpy as np
     import torch
     g = torch.Generator(device="cuda")
@@ -53,14 +53,18 @@ def eval_one(oz, O, h, kind, op_a, op_b, m, n, k, mode, reps, threshold=0.0, gpu
     b_shape = (n, k) if op_b == "N" else (k, n)
     A = gen(kind, a_shape, g)
     B = gen(kind, b_shape, g)
-    C = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+    if cplx:  # test/main_test.cu:195-202 fills 2x the doubles: both parts from the same distribution
+        A = torch.complex(A, gen(kind, a_shape, g))
+        B = torch.complex(B, gen(kind, b_shape, g))
+    C = torch.zeros((n, m), dtype=torch.complex128 if cplx else torch.float64, device="cuda")
     lda, ldb, ldc = a_shape[1], b_shape[1], m
+    ek = oz.complx if cplx else oz.real
 
     def call():
-        if mode == "dgemm":
+        if mode == "dgemm" and not cplx:
             st = oz.native_dgemm(h, op_a, op_b, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc)
         else:
-            st = oz.gemm(h, op_a, op_b, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc, mode)
+            st = oz.gemm(h, op_a, op_b, m, n, k, 1.0, A, lda, B, ldb, 0.0, C, ldc, mode, ek)
         if st:
             raise RuntimeError(f"gemm status {st}")
     call()
@@ -69,12 +73,16 @@ def eval_one(oz, O, h, kind, op_a, op_b, m, n, k, mode, reps, threshold=0.0, gpu
     rng = np.random.default_rng(1)
     rows = rng.integers(0, m, 2048)
     cols = rng.integers(0, n, 2048)
-    res = O.relative_residual_sampled(op_a, op_b, m, n, k, a_h, b_h, c_h, ns=2048, seed=1)
+    if cplx:
+        res = O.relative_residual_sampled_z(op_a, op_b, m, n, k, a_h, b_h, c_h, ns=2048, seed=1)
+    else:
+        res = O.relative_residual_sampled(op_a, op_b, m, n, k, a_h, b_h, c_h, ns=2048, seed=1)
     # max relative error on the same kind of sample (long double truth)
-    aa = (a_h[rows, :] if op_a == "N" else a_h[:, rows].T).astype(np.longdouble)
-    bb = (b_h[:, cols].T if op_b == "N" else b_h[cols, :]).astype(np.longdouble)
+    ld = np.clongdouble if cplx else np.longdouble
+    aa = (a_h[rows, :] if op_a == "N" else a_h[:, rows].T).astype(ld)
+    bb = (b_h[:, cols].T if op_b == "N" else b_h[cols, :]).astype(ld)
     truth = (aa * bb).sum(axis=1)
-    got = c_h[rows, cols].astype(np.longdouble)
+    got = c_h[rows, cols].astype(ld)
     max_rel = float(np.max(np.abs(got - truth) / np.maximum(np.abs(truth), np.finfo(np.float64).tiny)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -82,8 +90,8 @@ def eval_one(oz, O, h, kind, op_a, op_b, m, n, k, mode, reps, threshold=0.0, gpu
         call()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    tflops = 2.0 * m * n * k / dt / 1e12
-    print(f"{gpu_name},D,{kind},{mode},{op_a},{op_b},{m},{n},{k},{res:e},{max_rel:e},{tflops:e}", flush=True)
+    tflops = 2.0 * m * n * k / dt / 1e12 * (4 if cplx else 1)   # test/main_test.cu:140-141
+    print(f"{gpu_name},{'Z' if cplx else 'D'},{kind},{mode},{op_a},{op_b},{m},{n},{k},{res:e},{max_rel:e},{tflops:e}", flush=True)
     return res, tflops
 
 
@@ -102,16 +110,18 @@ def main():
     print("gpu,gemm,input,mode,opA,opB,m,n,k,residual,max_relative,throughput_in_tflops")
     try:
         if argv[0] == "ci_test":
-            # test/main_test.cu:702-746, real half: ops {N,T}^2 x {1023,1024,1025}^3 x fp64_int8_8..16, threshold 1e-15
+            # test/main_test.cu:702-746: ops {N,T}^2 x {1023,1024,1025}^3 x fp64_int8_8..16, real then complex,
+            # threshold 1e-15 (1944 GEMMs)
             passed = total = 0
-            for op_a in "NT":
+            for cplx in (False, True):
+              for op_a in "NT":
                 for op_b in "NT":
                     for m in (1023, 1024, 1025):
                         for n in (1023, 1024, 1025):
                             for k in (1023, 1024, 1025):
                                 for s in range(8, 17):
                                     r, _ = eval_one(oz, O, h, "urand01", op_a, op_b, m, n, k, f"fp64_int8_{s}", 1,
-                                                    gpu_name=name)
+                                                    gpu_name=name, cplx=cplx)
                                     total += 1
                                     if r < 1e-15:
                                         passed += 1
@@ -120,13 +130,13 @@ def main():
             print(f"PASSED {passed:5d} / {total:5d}")
             sys.exit(0 if passed == total else 1)
         kind, gemm, seq, start, end, step = argv[0], argv[1], argv[2], int(argv[3]), int(argv[4]), int(argv[5])
-        if gemm != "dgemm":
-            raise SystemExit("only dgemm (real) is implemented; zgemm is the next row (DESIGN.md)")
+        if gemm not in ("dgemm", "zgemm"):
+            raise SystemExit("gemm must be dgemm or zgemm")
         modes = argv[6:]
         sizes = [1 << e for e in range(start, end + 1, step)] if seq == "exp2" else list(range(start, end + 1, step))
         for nsz in sizes:
             for mode in modes:
-                eval_one(oz, O, h, kind, "N", "N", nsz, nsz, nsz, mode, ns.reps, gpu_name=name)
+                eval_one(oz, O, h, kind, "N", "N", nsz, nsz, nsz, mode, ns.reps, gpu_name=name, cplx=gemm == "zgemm")
     finally:
         torch.cuda.synchronize()
         oz.destroy(h)
