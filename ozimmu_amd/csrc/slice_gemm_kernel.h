@@ -27,14 +27,15 @@ constexpr int VAR_PF2 = 8;            // main loop with prefetch distance 2 (fra
 constexpr int VAR_NO_CU_SWIZZLE = 16; // plain (p%8, p/8) tile order inside a patch
 constexpr int VAR_PH_EVERY = 32;      // publish the phase hint every k-step
 constexpr int VAR_PH_LEAD2 = 64;      // late joiners start 2 k-steps ahead of the published phase
-constexpr int VAR_SADDR = 1024;       // staging: one address + M0 per 3 fragment blocks, immediate offsets 0/1024/2048
 constexpr int VAR_MUBUF = 2048;       // staging with buffer_load ... lds (SGPR resource) instead of global_load_lds
+constexpr int VAR_SADDR = 1024;       // staging: one address + M0 per 3 fragment blocks, immediate offsets 0/1024/2048
 constexpr int VAR_STATIC_PRIO = 4096; // odd/even workgroup generations get different s_setprio
+constexpr int VAR_KICK_PRIO = 8192;   // pseudo-random s_setprio per MFMA burst (breaks in-phase lock of co-resident workgroups)
 constexpr int VAR_SETPRIO = 128;      // s_setprio(1) around the MFMA burst of the prefetch-2 loop
 constexpr int VAR_TRACE = 512;        // record shader-clock stamps (SliceGemmArgs::trace), development only
 constexpr int VAR_INTERLEAVE = 256;   // prefetch-2 loop: issue the refill copies one per A-slice between the MFMAs
 // what the library ships (tools/gemm_ablate.hip A/B, N=8192 S=9: 18.9 ms vs 20.0 ms for VAR=0)
-constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2 | VAR_SADDR;
+constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2 | VAR_SADDR; // MUBUF staging: +5 % at 4096^3, -10 % at 16384^3
 
 // 2^e as a double, e in the normal range
 __device__ __forceinline__ double pow2d(int e) {
@@ -96,11 +97,10 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   const int8_t *src = (wave < WM) ? p.a_planes + (size_t)(WM * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
                                   : p.b_planes + (size_t)(2 * tn + (wave - WM)) * p.KB * (size_t)(S * FRAG_BYTES);
   const bool stager = wave < WM + 2; // WM = 4: waves 6,7 stage nothing
-  // MUBUF experiment: buffer resource over the whole plane, row-block offset as an SGPR
-  const int8_t *plane = (wave < WM) ? p.a_planes : p.b_planes;
-  const uint32_t plane_off = (uint32_t)(((wave < WM) ? (WM * tm + wave) : (2 * tn + (wave - WM))) * p.KB) * (uint32_t)(S * FRAG_BYTES);
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)plane, 0, 0x7fffffff, 0x00020000);
   const int8_t *src_u = src;                 // wave-uniform part (SGPRs)
+  // MUBUF staging: one buffer resource per wave over ITS row-block (K/32 * S KiB, always < 4 GiB), 32-bit offsets
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)src_u, 0, (int)(p.KB * (uint32_t)(S * FRAG_BYTES)), 0x00020000);
   const uint32_t lane_off = (uint32_t)lane * 16u; // per-lane part (one VGPR)
   src += lane * 16;
   v4i regstage[SL]; // VAR_GLOBAL_TO_REG only
@@ -117,8 +117,10 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     if (!stager) return;
     char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
     if constexpr ((VAR & VAR_MUBUF) != 0) {
-      // MUBUF form: SGPR resource + one VGPR lane offset + SGPR byte offset (experiment: cheaper issue under MFMA load?)
-      const uint32_t so = plane_off + kb * (uint32_t)(S * FRAG_BYTES);
+      // MUBUF form (buffer_load ... lds): SGPR resource + ONE lane-offset VGPR + SGPR byte offset.  Under MFMA load a
+      // wave issues these in ~60 cycles each, against ~140 for global_load_lds with a 64-bit VGPR address pair
+      // (tools/gemm_ablate.hip trace: stage issue 540 vs 1240 cycles per k-step)
+      const uint32_t so = kb * (uint32_t)(S * FRAG_BYTES);
 #pragma unroll
       for (int s = 0; s < SL; s++)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, lane_off,
@@ -242,6 +244,13 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
       }
       if (tr) trp[5] = clock64();
       if constexpr ((VAR & VAR_SETPRIO) != 0) __builtin_amdgcn_s_setprio(1);
+      if constexpr ((VAR & VAR_KICK_PRIO) != 0) {
+        // pseudo-random priority for this MFMA burst: if the partner workgroup's burst overlaps ours, one of the
+        // two wins the pipe outright about half of the time, which pushes the pair into the anti-phase state
+        // (one computes while the other stages) -- a state that then persists by itself
+        const uint32_t hsh = (blockIdx.x * 2654435761u + it * 40503u) >> 13;
+        if (__builtin_amdgcn_readfirstlane(hsh & 1u)) __builtin_amdgcn_s_setprio(2);
+      }
 #pragma unroll
       for (int i = 0; i < SL; i++) {
         if constexpr ((VAR & VAR_INTERLEAVE) != 0) {
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
       }
       if (refill) k_issue = koff_next(k_issue);
       if (tr) trp[6] = clock64();
-      if constexpr ((VAR & VAR_SETPRIO) != 0) __builtin_amdgcn_s_setprio(0);
+      if constexpr ((VAR & (VAR_SETPRIO | VAR_KICK_PRIO)) != 0) __builtin_amdgcn_s_setprio(0);
       cur ^= 1;
     }
   } else {

@@ -115,9 +115,7 @@ int main(int argc, char **argv) {
   };
   std::vector<Var> vars = {
       {"shipped 64x64", run<S, VAR_SHIPPED>, false, {}},
-      {"shipped + static prio", run<S, VAR_SHIPPED | VAR_STATIC_PRIO>, false, {}},
       {"MUBUF staging", run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>, false, {}},
-      {"MUBUF + static prio", run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF | VAR_STATIC_PRIO>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
@@ -150,7 +148,7 @@ int main(int argc, char **argv) {
     b.trace = tr;
     b.trace_block0 = (which & 2) ? 8192 : 0;
     if (which & 1)
-      run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF | VAR_STATIC_PRIO | VAR_TRACE>(b, st, e0, e1);
+      run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF | VAR_TRACE>(b, st, e0, e1);
     else
       run<S, VAR_SHIPPED | VAR_TRACE>(b, st, e0, e1);
     std::vector<unsigned long long> h(ntr);
