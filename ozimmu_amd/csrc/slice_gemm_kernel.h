@@ -20,6 +20,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int VAR_ABL_MASK = 7;
 constexpr int VAR_NO_GLOBAL = 1;
 constexpr int VAR_MFMA_ONLY = 2;
+constexpr int VAR_RAND_REGS = 16384; // with VAR_MFMA_ONLY: full-entropy operands (power / clock probe)
 constexpr int VAR_GLOBAL_NO_SYNC = 3; // staging issued but never waited for / no barrier (races; timing only)
 constexpr int VAR_SYNC_NO_GLOBAL = 4; // barrier every k-step but no staging
 constexpr int VAR_GLOBAL_TO_REG = 5;  // staging loads go to registers (no LDS-DMA write), never used
@@ -40,6 +41,58 @@ constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2 | VAR_SADDR; /
 // 2^e as a double, e in the normal range
 __device__ __forceinline__ double pow2d(int e) {
   return __longlong_as_double((long long)(1023 + e) << 52);
+}
+
+// ---- epilogue shared by the kernels: INT32 diagonal sums -> FP64 -> C ---------------------------------------
+// acc[d] holds, in the MFMA 32x32 C/D register layout (lane&31 = m, 16 registers = 16 different n), the sum of
+// the slice products with i+j = D0+d.  m: this lane's row of C; nbase: column of register 0.
+template <int D0, int ND>
+__device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, const v16i (&acc)[ND], uint32_t m,
+                                                    uint32_t nbase) {
+  if (p.dump) { // test hook: raw INT32 diagonal sums, [ND][N][M]
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
+      if (m < p.M && n < p.N)
+#pragma unroll
+        for (int d = 0; d < ND; d++) p.dump[((size_t)d * p.N + n) * p.M + m] = acc[d][r];
+    }
+    if (p.dump_only) return;
+  }
+  double sc[ND];
+#pragma unroll
+  for (int d = 0; d < ND; d++) sc[d] = pow2d(46 - p.L * (D0 + d + 2));
+  const bool mok = m < p.M;
+  const double ea = mok ? p.ea[m] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
+    if (!mok || n >= p.N) continue;
+    double x = p.acc_in ? p.acc[(size_t)n * p.M + m] : 0.0;
+#pragma unroll
+    for (int d = 0; d < ND; d++) x = fma((double)acc[d][r], sc[d], x);
+    if (!p.final) {
+      p.acc[(size_t)n * p.M + m] = x;
+    } else {
+      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
+      const double v = x * 0x1p-44 * ea * p.eb[n];
+      if (p.cplx) {
+        // one of the four real products of a ZGEMM: C += (alpha_re + i alpha_im) * v  (axy_complex_kernel,
+        // src/gemm.cu:160-186; C was scaled by beta beforehand, src/gemm.cu:199-239)
+        double2 *zp = reinterpret_cast<double2 *>(p.c) + ((size_t)n * p.ldc + m);
+        double2 y = *zp;
+        y.x = fma(p.alpha, v, y.x);
+        y.y = fma(p.alpha_im, v, y.y);
+        *zp = y;
+        continue;
+      }
+      double *cp = p.c + (size_t)n * p.ldc + m;
+      if (p.beta != 0.0)
+        *cp = fma(p.alpha, v, p.beta * *cp);
+      else
+        *cp = p.alpha * v;
+    }
+  }
 }
 
 // WM = A row-blocks (of 32 rows) per workgroup: 2 -> 4 waves, 64x64 tile, two workgroups per CU;
@@ -181,11 +234,26 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   }
   koff = __builtin_amdgcn_readfirstlane(koff);
 
-  v4i cf[2]; // MFMA-only ablation operands
+  constexpr bool RAND_REGS = (VAR & VAR_RAND_REGS) != 0;
+  constexpr int NCF = RAND_REGS ? SL : 2;
+  v4i cf[NCF]; // MFMA-only ablation operands
   if constexpr (ABL == VAR_MFMA_ONLY) {
-    cf[0] = v4i{lane, lane * 3, 7, 1};
-    cf[1] = v4i{lane * 5, 1, lane, 9};
-    asm volatile("" : "+v"(cf[0]), "+v"(cf[1]));
+    if constexpr (RAND_REGS) {
+#pragma unroll
+      for (int s = 0; s < NCF; s++) {
+        uint32_t x = (uint32_t)(lane * NCF + s) * 2654435761u + blockIdx.x;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+          cf[s][c] = (int)x;
+        }
+        asm volatile("" : "+v"(cf[s]));
+      }
+    } else {
+      cf[0] = v4i{lane, lane * 3, 7, 1};
+      cf[1] = v4i{lane * 5, 1, lane, 9};
+      asm volatile("" : "+v"(cf[0]), "+v"(cf[1]));
+    }
   }
 
   int cur = 0;
@@ -295,7 +363,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
         for (int j = 0; j < SL; j++) {
           const int d = i + j;
           if (d >= D0 && d < D0 + ND && d <= S - 1)
-            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf[j & 1], cf[i & 1], acc[d - D0], 0, 0, 0);
+            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf[RAND_REGS ? j : (j & 1)], cf[RAND_REGS ? i : (i & 1)], acc[d - D0], 0, 0, 0);
         }
     } else {
       v4i bf[SL];
@@ -317,52 +385,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   } // !VAR_PF2
 
   // ---- epilogue ------------------------------------------------------------------------------------
-  const uint32_t m = tm * (32 * WM) + wm * 32 + (lane & 31);
-  const uint32_t nbase = tn * 64 + wn * 32 + 4 * (lane >> 5);
-  if (p.dump) { // test hook: raw INT32 diagonal sums, [ND][N][M]
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
-      if (m < p.M && n < p.N)
-#pragma unroll
-        for (int d = 0; d < ND; d++) p.dump[((size_t)d * p.N + n) * p.M + m] = acc[d][r];
-    }
-    if (p.dump_only) return;
-  }
-  double sc[ND];
-#pragma unroll
-  for (int d = 0; d < ND; d++) sc[d] = pow2d(46 - p.L * (D0 + d + 2));
-  const bool mok = m < p.M;
-  const double ea = mok ? p.ea[m] : 0.0;
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
-    if (!mok || n >= p.N) continue;
-    double x = p.acc_in ? p.acc[(size_t)n * p.M + m] : 0.0;
-#pragma unroll
-    for (int d = 0; d < ND; d++) x = fma((double)acc[d][r], sc[d], x);
-    if (!p.final) {
-      p.acc[(size_t)n * p.M + m] = x;
-    } else {
-      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
-      const double v = x * 0x1p-44 * ea * p.eb[n];
-      if (p.cplx) {
-        // one of the four real products of a ZGEMM: C += (alpha_re + i alpha_im) * v  (axy_complex_kernel,
-        // src/gemm.cu:160-186; C was scaled by beta beforehand, src/gemm.cu:199-239)
-        double2 *zp = reinterpret_cast<double2 *>(p.c) + ((size_t)n * p.ldc + m);
-        double2 y = *zp;
-        y.x = fma(p.alpha, v, y.x);
-        y.y = fma(p.alpha_im, v, y.y);
-        *zp = y;
-        continue;
-      }
-      double *cp = p.c + (size_t)n * p.ldc + m;
-      if (p.beta != 0.0)
-        *cp = fma(p.alpha, v, p.beta * *cp);
-      else
-        *cp = p.alpha * v;
-    }
-  }
+  recombine_and_store<D0, ND>(p, acc, tm * (32 * WM) + wm * 32 + (lane & 31), tn * 64 + wn * 32 + 4 * (lane >> 5));
 }
 
 } // namespace ozhip

@@ -11,7 +11,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "slice_gemm_kernel.h"
+#include "slice_gemm_pp_kernel.h" // tools/: experiment, not part of the library
 
 using namespace ozhip;
 
@@ -52,6 +52,28 @@ static float run(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEven
   CK(hipMemsetAsync(a.phase, 0, 8 * 256, st));
   CK(hipEventRecord(e0, st));
   hipLaunchKernelGGL((slice_gemm_kernel<S, 0, S, VAR, WM>), dim3(a.tiles_m * a.tiles_n), dim3(128 * WM), lds, st, a);
+  CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms;
+}
+
+template <int S, int VAR>
+static float run_pp(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  constexpr size_t lds = 2 * 6 * S * FRAG_BYTES;
+  SliceGemmArgs a = a0;
+  a.tiles_m = (a.M + 63) / 64;
+  a.tiles_n = (a.N + 127) / 128;
+  static bool done = false;
+  if (!done) {
+    CK(hipFuncSetAttribute((const void *)slice_gemm_pp_kernel<S, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                           (int)lds));
+    done = true;
+  }
+  CK(hipMemsetAsync(a.phase, 0, 8 * 256, st));
+  CK(hipEventRecord(e0, st));
+  hipLaunchKernelGGL((slice_gemm_pp_kernel<S, VAR>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -115,8 +137,10 @@ int main(int argc, char **argv) {
   };
   std::vector<Var> vars = {
       {"shipped 64x64", run<S, VAR_SHIPPED>, false, {}},
-      {"MUBUF staging", run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>, false, {}},
+      {"ping-pong 64x128", run_pp<S, 0>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
+      {"mfma-only low-entropy regs", run<S, VAR_MFMA_ONLY>, false, {}},
+      {"mfma-only random regs", run<S, VAR_MFMA_ONLY | VAR_RAND_REGS>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
     for (auto &v : vars) {
@@ -131,46 +155,13 @@ int main(int argc, char **argv) {
     for (int which = 0; which < 3; which++) {
       CK(hipMemset(C, 0xFF, 8 * M * N));
       if (which == 0) run<S, VAR_SHIPPED>(a, st, e0, e1);
-      if (which == 1) run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>(a, st, e0, e1);
+      if (which == 1) run_pp<S, 0>(a, st, e0, e1);
       if (which == 2) run<S, VAR_SHIPPED | VAR_INTERLEAVE, 4>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
       for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
       std::printf("check variant %d vs plain loop: %zu mismatching elements of %zu\n", which, bad, M * N);
     }
-  }
-  for (int which = 0; which < 4; which++) { // per-phase trace: {global, MUBUF} x {first round, mid-kernel}
-    unsigned long long *tr;
-    const size_t ntr = 64 * 8 * 16 * 8;
-    CK(hipMalloc(&tr, ntr * 8));
-    CK(hipMemset(tr, 0, ntr * 8));
-    SliceGemmArgs b = a;
-    b.trace = tr;
-    b.trace_block0 = (which & 2) ? 8192 : 0;
-    if (which & 1)
-      run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF | VAR_TRACE>(b, st, e0, e1);
-    else
-      run<S, VAR_SHIPPED | VAR_TRACE>(b, st, e0, e1);
-    std::vector<unsigned long long> h(ntr);
-    CK(hipMemcpy(h.data(), tr, ntr * 8, hipMemcpyDeviceToHost));
-    const char *names[6] = {"wait vmcnt", "barrier A", "frag reads", "barrier B", "stage issue", "45 MFMA issue"};
-    double sum[6] = {0}, tot = 0;
-    int cnt = 0;
-    for (int blk = 0; blk < 64; blk++)
-      for (int w = 0; w < 4; w++)
-        for (int it = 0; it < 15; it++) {
-          const unsigned long long *t = &h[((size_t)(blk * 8 + w) * 16 + it) * 8];
-          const unsigned long long *tn = t + 8;
-          if (!t[0] || !tn[0]) continue;
-          for (int k = 0; k < 6; k++) sum[k] += (double)(t[k + 1] - t[k]);
-          tot += (double)(tn[0] - t[0]);
-          cnt++;
-        }
-    std::printf("trace %s, workgroups %u..: %.0f ticks per k-step (%d samples):", (which & 1) ? "MUBUF " : "global", b.trace_block0,
-                tot / cnt, cnt);
-    for (int k = 0; k < 6; k++) std::printf("  %s %.0f", names[k], sum[k] / cnt);
-    std::printf("\n");
-    CK(hipFree(tr));
   }
   const double ops = 45.0 * 2.0 * M * N * K;
   std::printf("N=%zu S=%d rounds=%d  (TOPS = 45*2*N^3 / t)\n", N, S, rounds);
