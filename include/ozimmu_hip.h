@@ -13,8 +13,11 @@
  *      rocblas_gemm_ex (all-f64_r case)                   <- cublasGemmEx   (src/cublas.cu:133-278)
  *      rocblas_dgemm_strided_batched                      <- cublasDgemmStridedBatched (src/cublas.cu:474-492)
  *      rocblas_zgemm, rocblas_gemm_ex (all-f64_c case)    <- cublasZgemm_v2 (src/cublas.cu:297-313)
- *      hipblasDgemm, hipblasGemmEx (HIP_R_64F case)       <- same, for applications that bind hipBLAS
- *                                                            directly (hipBLAS itself calls rocblas_dgemm)
+ *      rocblas_zgemm_strided_batched                      <- cublasZgemmStridedBatched (src/cublas.cu:494-512)
+ *      rocblas_gemm_strided_batched_ex (f64_r / f64_c)    <- cublasGemmStridedBatchedEx (src/cublas.cu:315-472)
+ *      hipblasDgemm, hipblasZgemm, hipblasGemmEx,         <- same, for applications that bind hipBLAS
+ *      hipblas{D,Z}gemmStridedBatched,                       directly (hipBLAS itself calls the rocBLAS
+ *      hipblasGemmStridedBatchedEx                           entry points above)
  *
  *    Environment (src/cublas.cu:18-48, :62-83; src/handle.cu:25-30; src/utils.hpp:88-115; README.md:54-77):
  *      OZIMMU_COMPUTE_MODE = dgemm | sgemm | fp64_int8_3..fp64_int8_18 | fp64_int8_auto  (read per call;
@@ -148,6 +151,16 @@ int ozimmu_hip_native_dgemm(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A,
                             size_t m, size_t n, size_t k, const double *alpha, const double *a_ptr,
                             size_t lda, const double *b_ptr, size_t ldb, const double *beta, double *c_ptr,
                             size_t ldc);
+
+/* the `sgemm` compute mode: C = f64( alpha32 * op(f32(A)) * op(f32(B)) + beta32 * f32(C) ) through the vendor
+ * SGEMM (real) / CGEMM (complex) -- mtk::ozimmu::dgemm_f32<T>, src/cublas_helper.cu:83-133, reached from the
+ * interposer at src/cublas.cu:169-186.  alpha/beta: host pointers to 1 (real) or 2 (complex) doubles.  C is not
+ * read when beta == 0.  The FP32 copies live in the handle's workspace ((mk + kn + mn) * 4 bytes, x2 complex).
+ * ozimmu_hip_gemm(..., OZIMMU_SGEMM, ...) forwards here (the reference's library entry throws for that mode).
+ * 0 ok, 1 bad arguments, 3 device/vendor failure. */
+int ozimmu_hip_gemm_f32(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
+                        size_t n, size_t k, const void *alpha, const void *a_ptr, size_t lda, const void *b_ptr,
+                        size_t ldb, const void *beta, void *c_ptr, size_t ldc, ozimmu_element_kind_t element_kind);
 
 /* timing of the last ozimmu_hip_gemm per stage in milliseconds (HIP events on the handle's stream; only
  * when profiling is enabled).  stages: 0 split_A, 1 split_B, 2 int8tc (fused with accumulate/copy) */

@@ -69,6 +69,8 @@ def lib():
     L.ozimmu_hip_working_memory_size.argtypes = [i, i, sz, sz, sz, i, i]
     L.ozimmu_hip_gemm.restype = i
     L.ozimmu_hip_gemm.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz, i, i]
+    L.ozimmu_hip_gemm_f32.restype = i
+    L.ozimmu_hip_gemm_f32.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz, i]
     L.ozimmu_hip_auto_mode_select.restype = i
     L.ozimmu_hip_auto_mode_select.argtypes = [vp, i, i, sz, sz, sz, vp, sz, vp, sz, i, d]
     L.ozimmu_hip_get_compute_mode_name_str.restype = C.c_char_p
@@ -201,6 +203,17 @@ def gemm(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr
     return int(lib().ozimmu_hip_gemm(handle.ptr, _op(op_A), _op(op_B), m, n, k, C.addressof(al), _ptr(a_ptr), lda,
                                      _ptr(b_ptr), ldb, C.addressof(be), _ptr(c_ptr), ldc, _mode(compute_mode),
                                      element_kind))
+
+
+def gemm_f32(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc, element_kind=real):
+    """mtk::ozimmu::dgemm_f32 (src/cublas_helper.cu:83-133): the `sgemm` compute mode."""
+    if element_kind == complx:
+        al = (C.c_double * 2)(complex(alpha).real, complex(alpha).imag)
+        be = (C.c_double * 2)(complex(beta).real, complex(beta).imag)
+    else:
+        al, be = C.c_double(alpha), C.c_double(beta)
+    return int(lib().ozimmu_hip_gemm_f32(handle.ptr, _op(op_A), _op(op_B), m, n, k, C.addressof(al), _ptr(a_ptr), lda,
+                                         _ptr(b_ptr), ldb, C.addressof(be), _ptr(c_ptr), ldc, element_kind))
 
 
 def native_dgemm(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc):

@@ -536,6 +536,75 @@ static int native_zgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_o
                     (rocblas_int)ldc);
 }
 
+// ---- `sgemm` compute mode (src/cublas_helper.cu:83-133) -------------------------------------------------------
+int ozimmu_hip_gemm_f32(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m, size_t n,
+                        size_t k, const void *alpha, const void *a, size_t lda, const void *b, size_t ldb,
+                        const void *beta, void *c, size_t ldc, ozimmu_element_kind_t element_kind) {
+  if (!h || !alpha || !beta) return 1;
+  if (check_gemm_shape(op_A, m, k, lda, "A") | check_gemm_shape(op_B, k, n, ldb, "B") |
+      check_gemm_shape(OZIMMU_OP_N, m, n, ldc, "C"))
+    return 1;
+  if (m == 0 || n == 0) return 0;
+  typedef rocblas_status (*create_t)(rocblas_handle *);
+  typedef rocblas_status (*set_stream_t)(rocblas_handle, hipStream_t);
+  typedef rocblas_status (*sgemm_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                    rocblas_int, const float *, const float *, rocblas_int, const float *, rocblas_int,
+                                    const float *, float *, rocblas_int);
+  typedef rocblas_status (*cgemm_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                    rocblas_int, const rocblas_float_complex *, const rocblas_float_complex *,
+                                    rocblas_int, const rocblas_float_complex *, rocblas_int,
+                                    const rocblas_float_complex *, rocblas_float_complex *, rocblas_int);
+  static create_t create = (create_t)vendor_symbol("rocblas_create_handle");
+  static set_stream_t set_stream = (set_stream_t)vendor_symbol("rocblas_set_stream");
+  static sgemm_t sgemm = (sgemm_t)vendor_symbol("rocblas_sgemm");
+  static cgemm_t cgemm = (cgemm_t)vendor_symbol("rocblas_cgemm");
+  if (!create || !set_stream || !sgemm || !cgemm) return 3;
+  std::lock_guard<std::mutex> lock(h->mtx);
+  if (!h->rocblas_handle) {
+    rocblas_handle rh = nullptr;
+    if (create(&rh) != rocblas_status_success) return 3;
+    h->rocblas_handle = rh;
+  }
+  const bool cplx = element_kind != OZIMMU_REAL;
+  const size_t w = cplx ? 2 : 1; // FP32 scalars per element
+  // workspace: A32 | B32 | C32, each 256-byte aligned (the reference packs them, :97-100)
+  const size_t a_bytes = align256(4 * w * m * k), b_bytes = align256(4 * w * k * n), c_bytes = align256(4 * w * m * n);
+  if (!ensure_workspace(h, a_bytes + b_bytes + c_bytes)) return 3;
+  float *a32 = (float *)h->working_memory_ptr;
+  float *b32 = (float *)((char *)h->working_memory_ptr + a_bytes);
+  float *c32 = (float *)((char *)h->working_memory_ptr + a_bytes + b_bytes);
+  // stored shapes (:102-106): A is m x k when op_A == N, else k x m; the FP32 copies are dense (ld = rows)
+  const size_t ar = op_A == OZIMMU_OP_N ? m : k, ac = op_A == OZIMMU_OP_N ? k : m;
+  const size_t br = op_B == OZIMMU_OP_N ? k : n, bc = op_B == OZIMMU_OP_N ? n : k;
+  const double *al = (const double *)alpha, *be = (const double *)beta;
+  const bool beta_zero = be[0] == 0 && (!cplx || be[1] == 0);
+  if (!hip_ok(launch_convert_f64_to_f32(a32, w * ar, (const double *)a, w * lda, w * ar, ac, h->stream), "convert A"))
+    return 3;
+  if (!hip_ok(launch_convert_f64_to_f32(b32, w * br, (const double *)b, w * ldb, w * br, bc, h->stream), "convert B"))
+    return 3;
+  if (!beta_zero && // :109-112
+      !hip_ok(launch_convert_f64_to_f32(c32, w * m, (const double *)c, w * ldc, w * m, n, h->stream), "convert C"))
+    return 3;
+  set_stream((rocblas_handle)h->rocblas_handle, h->stream);
+  rocblas_status st;
+  if (!cplx) {
+    const float al32 = (float)al[0], be32 = (float)be[0];
+    st = sgemm((rocblas_handle)h->rocblas_handle, to_rocblas_op(op_A), to_rocblas_op(op_B), (rocblas_int)m,
+               (rocblas_int)n, (rocblas_int)k, &al32, a32, (rocblas_int)ar, b32, (rocblas_int)br, &be32, c32,
+               (rocblas_int)m);
+  } else {
+    const rocblas_float_complex al32((float)al[0], (float)al[1]), be32((float)be[0], (float)be[1]);
+    st = cgemm((rocblas_handle)h->rocblas_handle, to_rocblas_op(op_A), to_rocblas_op(op_B), (rocblas_int)m,
+               (rocblas_int)n, (rocblas_int)k, &al32, (const rocblas_float_complex *)a32, (rocblas_int)ar,
+               (const rocblas_float_complex *)b32, (rocblas_int)br, &be32, (rocblas_float_complex *)c32,
+               (rocblas_int)m);
+  }
+  if (st != rocblas_status_success) return 3;
+  if (!hip_ok(launch_convert_f32_to_f64((double *)c, w * ldc, c32, w * m, w * m, n, h->stream), "convert C back"))
+    return 3;
+  return 0;
+}
+
 // real: a/b are double arrays; complex (src/split.cu:367-374): Re and Im counted separately, same 16 counters
 static int mantissa_loss_impl(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
                               size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb, bool cplx,
@@ -620,9 +689,11 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
              ", threshold average mantissa loss = " + std::to_string(h->avg_mantissa_loss_threshold));
     return ozimmu_hip_gemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, auto_mode, element_kind);
   }
+  if (mode == OZIMMU_SGEMM) // src/cublas.cu:169-186 (the reference's library entry throws NOT_IMPLEMENTED here)
+    return ozimmu_hip_gemm_f32(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, element_kind);
   const int S = num_split_of_mode(mode);
   if (S == 0 || (k == 0 && !cplx)) {
-    // `dgemm` (src/gemm.cu:639-645); `sgemm` (FP32 emulation, out of scope) and k == 0 also go native
+    // `dgemm` (src/gemm.cu:639-645); k == 0 also goes native
     const int st = cplx ? native_zgemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc)
                         : ozimmu_hip_native_dgemm(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a,
                                                   lda, (const double *)b, ldb, (const double *)beta, (double *)c, ldc);

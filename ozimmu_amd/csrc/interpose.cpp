@@ -4,8 +4,11 @@
 //   cublasCreate_v2 / cublasDestroy_v2   (:104-131)  -> rocblas_create_handle / rocblas_destroy_handle
 //   cublasGemmEx                         (:133-278)  -> rocblas_gemm_ex, hipblasGemmEx (all-FP64 real case)
 //   cublasDgemm_v2                       (:280-295)  -> rocblas_dgemm, rocblas_dgemm_64, hipblasDgemm
-//   cublasDgemmStridedBatched            (:474-492)  -> rocblas_dgemm_strided_batched (sequential loop, :380-406)
-//   cublasZgemm_v2                       (:297-313)  -> rocblas_zgemm (and the f64_c case of rocblas_gemm_ex)
+//   cublasDgemmStridedBatched            (:474-492)  -> rocblas_dgemm_strided_batched, hipblasDgemmStridedBatched (sequential loop, :380-406)
+//   cublasZgemm_v2                       (:297-313)  -> rocblas_zgemm, hipblasZgemm (and the f64_c case of rocblas_gemm_ex)
+//   cublasZgemmStridedBatched            (:494-512)  -> rocblas_zgemm_strided_batched, hipblasZgemmStridedBatched
+//   cublasGemmStridedBatchedEx           (:315-472)  -> rocblas_gemm_strided_batched_ex, hipblasGemmStridedBatchedEx
+//   sgemm compute mode                   (:169-186, :355-376) -> ozimmu_hip_gemm_f32 (FP32 vendor GEMM on converted copies)
 // Originals are found with dlsym(RTLD_NEXT) (src/utils.hpp:117-141).
 //
 // Documented deviations from the reference (SURVEY.md §8a "quirks"):
@@ -89,7 +92,7 @@ bool try_ozaki(hipStream_t stream, bool host_pointer_mode, ozimmu_operation_t op
                const void *B, long long ldb, const void *beta, void *C, long long ldc, bool cplx = false) {
   if (t_depth > 0) return false;
   const ozimmu_compute_mode_t mode = get_compute_mode();
-  if (mode == OZIMMU_DGEMM || mode == OZIMMU_SGEMM) return false; // sgemm emulation: out of scope -> native
+  if (mode == OZIMMU_DGEMM) return false;
   if (!host_pointer_mode || m < 0 || n < 0 || k < 0 || !alpha || !beta) return false;
   ozimmu_hip_handle_t h = get_global_handle();
   if (!h) return false;
@@ -153,6 +156,22 @@ bool hipblas_ctx(hipblasHandle_t handle, hipStream_t *stream, bool *host_mode) {
 }
 
 ozimmu_operation_t hb_to_oz(hipblasOperation_t op) { return op == HIPBLAS_OP_N ? OZIMMU_OP_N : OZIMMU_OP_T; }
+
+// Strided-batched entry points: a sequential loop over the batch like src/cublas.cu:380-406.  `ozaki(i)` runs
+// matrix i through try_ozaki; if the predicate rejects the first matrix nothing has been touched and the caller
+// forwards the whole batch to the vendor routine (returns -1); if a later matrix fails, the remainder is finished
+// with the vendor's non-batched routine `native(i)`.
+template <class Ozaki, class Native> int run_batch(long long batch_count, Ozaki ozaki, Native native) {
+  long long done = 0;
+  for (; done < batch_count; done++)
+    if (!ozaki(done)) break;
+  if (done == batch_count) return 0;
+  if (done == 0) return -1;
+  DepthGuard guard;
+  for (; done < batch_count; done++)
+    if (const int st = native(done)) return st;
+  return 0;
+}
 
 } // namespace
 
@@ -282,27 +301,22 @@ rocblas_status rocblas_dgemm_strided_batched(rocblas_handle handle, rocblas_oper
   bool host_mode = false;
   if (t_depth == 0 && batch_count > 0 && get_compute_mode() != OZIMMU_DGEMM &&
       rocblas_ctx(handle, &stream, &host_mode)) {
-    // sequential loop over the batch like src/cublas.cu:380-406; all-or-nothing on the first matrix
-    int done = 0;
-    for (; done < batch_count; done++)
-      if (!try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A + (size_t)done * stride_a, lda,
-                     B + (size_t)done * stride_b, ldb, beta, C + (size_t)done * stride_c, ldc))
-        break;
-    if (done == batch_count) return rocblas_status_success;
-    if (done > 0) { // finish the remainder natively, one matrix at a time
-      typedef rocblas_status (*dg_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                     rocblas_int, const double *, const double *, rocblas_int, const double *,
-                                     rocblas_int, const double *, double *, rocblas_int);
-      static dg_t dg = original<dg_t>("rocblas_dgemm");
-      if (!dg) return rocblas_status_internal_error;
-      DepthGuard guard;
-      for (; done < batch_count; done++) {
-        const rocblas_status st = dg(handle, transA, transB, m, n, k, alpha, A + (size_t)done * stride_a, lda,
-                                     B + (size_t)done * stride_b, ldb, beta, C + (size_t)done * stride_c, ldc);
-        if (st != rocblas_status_success) return st;
-      }
-      return rocblas_status_success;
-    }
+    typedef rocblas_status (*dg_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                   rocblas_int, const double *, const double *, rocblas_int, const double *,
+                                   rocblas_int, const double *, double *, rocblas_int);
+    static dg_t dg = original<dg_t>("rocblas_dgemm");
+    const int st = run_batch(
+        batch_count,
+        [&](long long i) {
+          return try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A + i * stride_a, lda,
+                           B + i * stride_b, ldb, beta, C + i * stride_c, ldc);
+        },
+        [&](long long i) {
+          return dg ? (int)dg(handle, transA, transB, m, n, k, alpha, A + i * stride_a, lda, B + i * stride_b, ldb,
+                              beta, C + i * stride_c, ldc)
+                    : (int)rocblas_status_internal_error;
+        });
+    if (st >= 0) return (rocblas_status)st;
   }
   if (!fn) return rocblas_status_internal_error;
   DepthGuard guard;
@@ -331,6 +345,111 @@ rocblas_status rocblas_zgemm(rocblas_handle handle, rocblas_operation transA, ro
   if (!fn) return rocblas_status_internal_error;
   DepthGuard guard;
   return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+// cublasZgemmStridedBatched (src/cublas.cu:494-512)
+rocblas_status rocblas_zgemm_strided_batched(rocblas_handle handle, rocblas_operation transA,
+                                             rocblas_operation transB, rocblas_int m, rocblas_int n, rocblas_int k,
+                                             const rocblas_double_complex *alpha, const rocblas_double_complex *A,
+                                             rocblas_int lda, rocblas_stride stride_a,
+                                             const rocblas_double_complex *B, rocblas_int ldb,
+                                             rocblas_stride stride_b, const rocblas_double_complex *beta,
+                                             rocblas_double_complex *C, rocblas_int ldc, rocblas_stride stride_c,
+                                             rocblas_int batch_count) {
+  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                 rocblas_int, const rocblas_double_complex *, const rocblas_double_complex *,
+                                 rocblas_int, rocblas_stride, const rocblas_double_complex *, rocblas_int,
+                                 rocblas_stride, const rocblas_double_complex *, rocblas_double_complex *, rocblas_int,
+                                 rocblas_stride, rocblas_int);
+  static fn_t fn = original<fn_t>("rocblas_zgemm_strided_batched");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  const bool no_conj = transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
+  if (t_depth == 0 && no_conj && batch_count > 0 && get_compute_mode() != OZIMMU_DGEMM &&
+      rocblas_ctx(handle, &stream, &host_mode)) {
+    typedef rocblas_status (*zg_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                   rocblas_int, const rocblas_double_complex *, const rocblas_double_complex *,
+                                   rocblas_int, const rocblas_double_complex *, rocblas_int,
+                                   const rocblas_double_complex *, rocblas_double_complex *, rocblas_int);
+    static zg_t zg = original<zg_t>("rocblas_zgemm");
+    const int st = run_batch(
+        batch_count,
+        [&](long long i) {
+          return try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A + i * stride_a, lda,
+                           B + i * stride_b, ldb, beta, C + i * stride_c, ldc, true);
+        },
+        [&](long long i) {
+          return zg ? (int)zg(handle, transA, transB, m, n, k, alpha, A + i * stride_a, lda, B + i * stride_b, ldb,
+                              beta, C + i * stride_c, ldc)
+                    : (int)rocblas_status_internal_error;
+        });
+    if (st >= 0) return (rocblas_status)st;
+  }
+  if (!fn) return rocblas_status_internal_error;
+  DepthGuard guard;
+  return fn(handle, transA, transB, m, n, k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c,
+            batch_count);
+}
+
+// cublasGemmStridedBatchedEx (src/cublas.cu:315-472): all-FP64 real or all-FP64 complex, in place (C == D).
+// The name is parenthesised because rocblas.h also defines a backward-compatibility macro of the same name.
+rocblas_status (rocblas_gemm_strided_batched_ex)(rocblas_handle handle, rocblas_operation transA,
+                                                 rocblas_operation transB, rocblas_int m, rocblas_int n,
+                                                 rocblas_int k, const void *alpha, const void *a,
+                                                 rocblas_datatype a_type, rocblas_int lda, rocblas_stride stride_a,
+                                                 const void *b, rocblas_datatype b_type, rocblas_int ldb,
+                                                 rocblas_stride stride_b, const void *beta, const void *c,
+                                                 rocblas_datatype c_type, rocblas_int ldc, rocblas_stride stride_c,
+                                                 void *d, rocblas_datatype d_type, rocblas_int ldd,
+                                                 rocblas_stride stride_d, rocblas_int batch_count,
+                                                 rocblas_datatype compute_type, rocblas_gemm_algo algo,
+                                                 int32_t solution_index, uint32_t flags) {
+  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                 rocblas_int, const void *, const void *, rocblas_datatype, rocblas_int,
+                                 rocblas_stride, const void *, rocblas_datatype, rocblas_int, rocblas_stride,
+                                 const void *, const void *, rocblas_datatype, rocblas_int, rocblas_stride, void *,
+                                 rocblas_datatype, rocblas_int, rocblas_stride, rocblas_int, rocblas_datatype,
+                                 rocblas_gemm_algo, int32_t, uint32_t);
+  static fn_t fn = original<fn_t>("rocblas_gemm_strided_batched_ex");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  const bool in_place = c == d && ldc == ldd && stride_c == stride_d;
+  const bool f64 = a_type == rocblas_datatype_f64_r && b_type == rocblas_datatype_f64_r &&
+                   c_type == rocblas_datatype_f64_r && d_type == rocblas_datatype_f64_r &&
+                   compute_type == rocblas_datatype_f64_r && in_place;
+  const bool c64 = a_type == rocblas_datatype_f64_c && b_type == rocblas_datatype_f64_c &&
+                   c_type == rocblas_datatype_f64_c && d_type == rocblas_datatype_f64_c &&
+                   compute_type == rocblas_datatype_f64_c && in_place &&
+                   transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
+  if (t_depth == 0 && (f64 || c64) && batch_count > 0 && get_compute_mode() != OZIMMU_DGEMM &&
+      rocblas_ctx(handle, &stream, &host_mode)) {
+    typedef rocblas_status (*ex_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
+                                   rocblas_int, const void *, const void *, rocblas_datatype, rocblas_int,
+                                   const void *, rocblas_datatype, rocblas_int, const void *, const void *,
+                                   rocblas_datatype, rocblas_int, void *, rocblas_datatype, rocblas_int,
+                                   rocblas_datatype, rocblas_gemm_algo, int32_t, uint32_t);
+    static ex_t ex = original<ex_t>("rocblas_gemm_ex");
+    const size_t es = c64 ? 16 : 8;
+    const char *ap = (const char *)a, *bp = (const char *)b;
+    char *dp = (char *)d;
+    const int st = run_batch(
+        batch_count,
+        [&](long long i) {
+          return try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, ap + i * stride_a * es, lda,
+                           bp + i * stride_b * es, ldb, beta, dp + i * stride_d * es, ldd, c64);
+        },
+        [&](long long i) {
+          return ex ? (int)ex(handle, transA, transB, m, n, k, alpha, ap + i * stride_a * es, a_type, lda,
+                              bp + i * stride_b * es, b_type, ldb, beta, dp + i * stride_d * es, c_type, ldc,
+                              dp + i * stride_d * es, d_type, ldd, compute_type, algo, solution_index, flags)
+                    : (int)rocblas_status_internal_error;
+        });
+    if (st >= 0) return (rocblas_status)st;
+  }
+  if (!fn) return rocblas_status_internal_error;
+  DepthGuard guard;
+  return fn(handle, transA, transB, m, n, k, alpha, a, a_type, lda, stride_a, b, b_type, ldb, stride_b, beta, c,
+            c_type, ldc, stride_c, d, d_type, ldd, stride_d, batch_count, compute_type, algo, solution_index, flags);
 }
 
 // ---- hipBLAS (only reached when an application binds hipBLAS statically or resolves these first) --------
@@ -371,6 +490,145 @@ hipblasStatus_t hipblasGemmEx(hipblasHandle_t handle, hipblasOperation_t transA,
   if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
   return fn(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType,
             algo);
+}
+
+// The remaining hipBLAS twins.  They never run the Ozaki path themselves twice: when the predicate rejects a call
+// the vendor hipBLAS routine forwards to the rocBLAS entry point above, which is the normal intercept point.
+hipblasStatus_t hipblasZgemm(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m,
+                             int n, int k, const hipDoubleComplex *alpha, const hipDoubleComplex *AP, int lda,
+                             const hipDoubleComplex *BP, int ldb, const hipDoubleComplex *beta, hipDoubleComplex *CP,
+                             int ldc) {
+  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                  const hipDoubleComplex *, const hipDoubleComplex *, int, const hipDoubleComplex *,
+                                  int, const hipDoubleComplex *, hipDoubleComplex *, int);
+  static fn_t fn = original<fn_t>("hipblasZgemm");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  const bool no_conj = transA != HIPBLAS_OP_C && transB != HIPBLAS_OP_C;
+  if (t_depth == 0 && no_conj && get_compute_mode() != OZIMMU_DGEMM && hipblas_ctx(handle, &stream, &host_mode) &&
+      try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP, lda, BP, ldb, beta, CP, ldc,
+                true))
+    return HIPBLAS_STATUS_SUCCESS;
+  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
+  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, BP, ldb, beta, CP, ldc);
+}
+
+hipblasStatus_t hipblasDgemmStridedBatched(hipblasHandle_t handle, hipblasOperation_t transA,
+                                           hipblasOperation_t transB, int m, int n, int k, const double *alpha,
+                                           const double *AP, int lda, long long strideA, const double *BP, int ldb,
+                                           long long strideB, const double *beta, double *CP, int ldc,
+                                           long long strideC, int batchCount) {
+  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                  const double *, const double *, int, long long, const double *, int, long long,
+                                  const double *, double *, int, long long, int);
+  static fn_t fn = original<fn_t>("hipblasDgemmStridedBatched");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  if (t_depth == 0 && batchCount > 0 && get_compute_mode() != OZIMMU_DGEMM &&
+      hipblas_ctx(handle, &stream, &host_mode)) {
+    typedef hipblasStatus_t (*dg_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                    const double *, const double *, int, const double *, int, const double *, double *,
+                                    int);
+    static dg_t dg = original<dg_t>("hipblasDgemm");
+    const int st = run_batch(
+        batchCount,
+        [&](long long i) {
+          return try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP + i * strideA, lda,
+                           BP + i * strideB, ldb, beta, CP + i * strideC, ldc);
+        },
+        [&](long long i) {
+          return dg ? (int)dg(handle, transA, transB, m, n, k, alpha, AP + i * strideA, lda, BP + i * strideB, ldb, beta,
+                              CP + i * strideC, ldc)
+                    : (int)HIPBLAS_STATUS_INTERNAL_ERROR;
+        });
+    if (st >= 0) return (hipblasStatus_t)st;
+  }
+  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
+  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, strideA, BP, ldb, strideB, beta, CP, ldc, strideC,
+            batchCount);
+}
+
+hipblasStatus_t hipblasZgemmStridedBatched(hipblasHandle_t handle, hipblasOperation_t transA,
+                                           hipblasOperation_t transB, int m, int n, int k,
+                                           const hipDoubleComplex *alpha, const hipDoubleComplex *AP, int lda,
+                                           long long strideA, const hipDoubleComplex *BP, int ldb, long long strideB,
+                                           const hipDoubleComplex *beta, hipDoubleComplex *CP, int ldc,
+                                           long long strideC, int batchCount) {
+  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                  const hipDoubleComplex *, const hipDoubleComplex *, int, long long,
+                                  const hipDoubleComplex *, int, long long, const hipDoubleComplex *, hipDoubleComplex *,
+                                  int, long long, int);
+  static fn_t fn = original<fn_t>("hipblasZgemmStridedBatched");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  const bool no_conj = transA != HIPBLAS_OP_C && transB != HIPBLAS_OP_C;
+  if (t_depth == 0 && no_conj && batchCount > 0 && get_compute_mode() != OZIMMU_DGEMM &&
+      hipblas_ctx(handle, &stream, &host_mode)) {
+    typedef hipblasStatus_t (*zg_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                    const hipDoubleComplex *, const hipDoubleComplex *, int, const hipDoubleComplex *,
+                                    int, const hipDoubleComplex *, hipDoubleComplex *, int);
+    static zg_t zg = original<zg_t>("hipblasZgemm");
+    const int st = run_batch(
+        batchCount,
+        [&](long long i) {
+          return try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP + i * strideA, lda,
+                           BP + i * strideB, ldb, beta, CP + i * strideC, ldc, true);
+        },
+        [&](long long i) {
+          return zg ? (int)zg(handle, transA, transB, m, n, k, alpha, AP + i * strideA, lda, BP + i * strideB, ldb, beta,
+                              CP + i * strideC, ldc)
+                    : (int)HIPBLAS_STATUS_INTERNAL_ERROR;
+        });
+    if (st >= 0) return (hipblasStatus_t)st;
+  }
+  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
+  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, strideA, BP, ldb, strideB, beta, CP, ldc, strideC,
+            batchCount);
+}
+
+hipblasStatus_t hipblasGemmStridedBatchedEx(hipblasHandle_t handle, hipblasOperation_t transA,
+                                            hipblasOperation_t transB, int m, int n, int k, const void *alpha,
+                                            const void *A, hipDataType aType, int lda, hipblasStride strideA,
+                                            const void *B, hipDataType bType, int ldb, hipblasStride strideB,
+                                            const void *beta, void *C, hipDataType cType, int ldc,
+                                            hipblasStride strideC, int batchCount, hipblasComputeType_t computeType,
+                                            hipblasGemmAlgo_t algo) {
+  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                  const void *, const void *, hipDataType, int, hipblasStride, const void *,
+                                  hipDataType, int, hipblasStride, const void *, void *, hipDataType, int,
+                                  hipblasStride, int, hipblasComputeType_t, hipblasGemmAlgo_t);
+  static fn_t fn = original<fn_t>("hipblasGemmStridedBatchedEx");
+  hipStream_t stream = nullptr;
+  bool host_mode = false;
+  const bool f64 = aType == HIP_R_64F && bType == HIP_R_64F && cType == HIP_R_64F && computeType == HIPBLAS_COMPUTE_64F;
+  const bool c64 = aType == HIP_C_64F && bType == HIP_C_64F && cType == HIP_C_64F &&
+                   computeType == HIPBLAS_COMPUTE_64F && transA != HIPBLAS_OP_C && transB != HIPBLAS_OP_C;
+  if (t_depth == 0 && (f64 || c64) && batchCount > 0 && get_compute_mode() != OZIMMU_DGEMM &&
+      hipblas_ctx(handle, &stream, &host_mode)) {
+    typedef hipblasStatus_t (*ex_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
+                                    const void *, const void *, hipDataType, int, const void *, hipDataType, int,
+                                    const void *, void *, hipDataType, int, hipblasComputeType_t, hipblasGemmAlgo_t);
+    static ex_t ex = original<ex_t>("hipblasGemmEx");
+    const size_t es = c64 ? 16 : 8;
+    const char *ap = (const char *)A, *bp = (const char *)B;
+    char *cp = (char *)C;
+    const int st = run_batch(
+        batchCount,
+        [&](long long i) {
+          return try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, ap + i * strideA * es,
+                           lda, bp + i * strideB * es, ldb, beta, cp + i * strideC * es, ldc, c64);
+        },
+        [&](long long i) {
+          return ex ? (int)ex(handle, transA, transB, m, n, k, alpha, ap + i * strideA * es, aType, lda,
+                              bp + i * strideB * es, bType, ldb, beta, cp + i * strideC * es, cType, ldc, computeType,
+                              algo)
+                    : (int)HIPBLAS_STATUS_INTERNAL_ERROR;
+        });
+    if (st >= 0) return (hipblasStatus_t)st;
+  }
+  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
+  return fn(handle, transA, transB, m, n, k, alpha, A, aType, lda, strideA, B, bType, ldb, strideB, beta, C, cType, ldc,
+            strideC, batchCount, computeType, algo);
 }
 
 } // extern "C"

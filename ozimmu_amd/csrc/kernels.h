@@ -63,4 +63,11 @@ hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int
 hipError_t launch_mantissa_loss(const OperandView &v, const uint32_t *exps, int L,
                                 unsigned long long *counters, hipStream_t stream);
 
+// ---- convert.hip: the `sgemm` compute mode (src/cublas_helper.cu:20-66) ---------------------------------
+// column-major rows x cols scalars; complex matrices pass rows = 2 * complex rows and ld = 2 * complex ld
+hipError_t launch_convert_f64_to_f32(float *dst, size_t ldd, const double *src, size_t lds, size_t rows, size_t cols,
+                                     hipStream_t stream);
+hipError_t launch_convert_f32_to_f64(double *dst, size_t ldd, const float *src, size_t lds, size_t rows, size_t cols,
+                                     hipStream_t stream);
+
 } // namespace ozhip

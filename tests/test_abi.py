@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ozimmu_hip.h")
 
 INTERPOSED = ["rocblas_create_handle", "rocblas_destroy_handle", "rocblas_dgemm", "rocblas_dgemm_64",
-              "rocblas_gemm_ex", "rocblas_dgemm_strided_batched", "rocblas_zgemm", "hipblasDgemm", "hipblasGemmEx"]
+              "rocblas_gemm_ex", "rocblas_dgemm_strided_batched", "rocblas_zgemm", "rocblas_zgemm_strided_batched",
+              "rocblas_gemm_strided_batched_ex", "hipblasDgemm", "hipblasGemmEx", "hipblasZgemm",
+              "hipblasDgemmStridedBatched", "hipblasZgemmStridedBatched", "hipblasGemmStridedBatchedEx"]
 
 
 @pytest.fixture(scope="module")

@@ -82,6 +82,16 @@ int main(int argc, char** argv) {
   hipStreamSynchronize(st);
   hipMemcpy(C.data(), dC + (size_t)2 * m * n, C.size() * 8, hipMemcpyDeviceToHost);
   printf("RESIDUAL strided_batched %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  // 4. rocblas_gemm_strided_batched_ex, all f64, in place, 2 matrices
+  for (int b = 0; b < 2; b++) hipMemcpy(dC + (size_t)b * m * n, C0.data(), C.size() * 8, hipMemcpyHostToDevice);
+  if (rocblas_gemm_strided_batched_ex(h, oa, ob, m, n, k, &alpha, dA, rocblas_datatype_f64_r, lda, 0, dB,
+                                      rocblas_datatype_f64_r, ldb, 0, &beta, dC, rocblas_datatype_f64_r, m,
+                                      (rocblas_stride)m * n, dC, rocblas_datatype_f64_r, m, (rocblas_stride)m * n, 2,
+                                      rocblas_datatype_f64_r, rocblas_gemm_algo_standard, 0, 0) != rocblas_status_success)
+    return 6;
+  hipStreamSynchronize(st);
+  hipMemcpy(C.data(), dC + (size_t)1 * m * n, C.size() * 8, hipMemcpyDeviceToHost);
+  printf("RESIDUAL strided_batched_ex %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
   rocblas_destroy_handle(h);
   return 0;
 }
@@ -115,7 +125,7 @@ def test_preloaded_rocblas_dgemm_runs_the_ozaki_path(driver, ta, tb):
     assert all(v < 1e-14 for v in native.values())
     oz, out = run(driver, [512, ta, tb], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_9",
                   OZIMMU_INFO=1, OZIMMU_ENABLE_CULIP_PROFILING=1, **thr)
-    assert set(oz) == {"dgemm", "gemm_ex", "strided_batched"}
+    assert set(oz) == {"dgemm", "gemm_ex", "strided_batched", "strided_batched_ex"}
     assert all(v < 1e-15 for v in oz.values()), oz           # the reference's gate, through the preload
     assert "[ozIMMU LOG] Reallocated memory" in out           # src/handle.cu:69
     # CULiP line format of src/cublas.cu:157-162 / src/culip.cu:19-39
@@ -133,6 +143,15 @@ def test_thresholds_and_mode_gate_the_intercept(driver):
     assert all(v < 1e-14 for v in res.values())               # native accuracy, not the 4-slice error
     res, _ = run(driver, [512, 0, 0], LD_PRELOAD=ozimmu_amd.LIB_PATH)
     assert all(v < 1e-14 for v in res.values())
+
+
+def test_sgemm_mode_through_the_preload(driver):
+    """OZIMMU_COMPUTE_MODE=sgemm (README.md:34; src/cublas.cu:169-186): FP32 accuracy, CULiP tag `Dsgemm`"""
+    thr = dict(OZIMMU_INTERCEPT_THRESHOLD_M=256, OZIMMU_INTERCEPT_THRESHOLD_N=256, OZIMMU_INTERCEPT_THRESHOLD_K=256)
+    res, out = run(driver, [512, 1, 0], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="sgemm",
+                   OZIMMU_ENABLE_CULIP_PROFILING=1, **thr)
+    assert all(1e-9 < v < 1e-5 for v in res.values()), res
+    assert "[CULiP Result][Dsgemm-TN-m512-n576-k544]" in out
 
 
 def test_auto_mode_through_the_preload(driver):
@@ -166,3 +185,32 @@ def test_pytorch_float64_matmul_is_intercepted():
     diff10 = float([l for l in p10.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()[1])
     assert "[ozIMMU LOG]" in p.stdout
     assert diff3 > 1e-6 and diff10 < 1e-11, (diff3, diff10)    # 3 slices are visibly coarse, 10 are FP64-accurate
+
+
+def test_pytorch_batched_matmul_is_intercepted():
+    """torch.bmm(float64 / complex128) -> hipblas{D,Z}gemmStridedBatched -> rocblas_{d,z}gemm_strided_batched -> shim
+    (cublasDgemmStridedBatched / cublasZgemmStridedBatched, src/cublas.cu:474-512)"""
+    code = textwrap.dedent("""
+        import torch
+        torch.manual_seed(0)
+        a = torch.rand(3, 1100, 1024, dtype=torch.float64, device="cuda") * 2 - 1
+        b = torch.rand(3, 1024, 1050, dtype=torch.float64, device="cuda") * 2 - 1
+        c = torch.bmm(a, b)
+        z = torch.bmm(torch.complex(a, a.flip(0)), torch.complex(b, -b.flip(0)))
+        torch.cuda.synchronize()
+        ref = torch.bmm(a.cpu(), b.cpu())
+        zref = torch.bmm(torch.complex(a, a.flip(0)).cpu(), torch.complex(b, -b.flip(0)).cpu())
+        print("MAXDIFF %.3e %.3e" % ((c.cpu() - ref).abs().max().item(), (z.cpu() - zref).abs().max().item()))
+    """)
+    diffs = {}
+    for mode in ("fp64_int8_3", "fp64_int8_10"):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
+        e.update(LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE=mode, OZIMMU_ENABLE_CULIP_PROFILING="1")
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stdout + p.stderr
+        line = [l for l in p.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()
+        diffs[mode] = (float(line[1]), float(line[2]), p.stdout)
+    assert diffs["fp64_int8_3"][0] > 1e-6 and diffs["fp64_int8_3"][1] > 1e-6, diffs["fp64_int8_3"][:2]
+    assert diffs["fp64_int8_10"][0] < 1e-11 and diffs["fp64_int8_10"][1] < 1e-11, diffs["fp64_int8_10"][:2]
+    out = diffs["fp64_int8_10"][2]
+    assert out.count("[CULiP Result][Dfp64_int8_10-") == 3 and out.count("[CULiP Result][Zfp64_int8_10-") == 3, out

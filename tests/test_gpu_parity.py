@@ -295,3 +295,47 @@ def test_hip_path_reproduces_golden(oz, path):
     sel = int(g["auto_selected"])
     mode = m_.auto_mode_select(h, op_a, op_b, m, n, k, a, lda, b, ldb, m_.real, 1.5)
     assert mode == (m_.dgemm if sel == 0 else m_.fp64_int8_3 + sel - 3)
+
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_sgemm_mode_matches_an_fp32_product(oz, op_a, op_b, cplx):
+    """the `sgemm` compute mode (src/cublas_helper.cu:83-133): C = f64(alpha32 * f32(A) f32(B) + beta32 * f32(C)).
+    The vendor SGEMM's summation order is its own, so the tolerance is FP32's (a few k * 2^-24 relative to |A||B|);
+    every stored value must be exactly representable in FP32, and the padding rows of C stay untouched."""
+    m_, h = oz
+    m, n, k = 150, 70, 333
+    rng = np.random.default_rng(7)
+    dt = np.complex128 if cplx else np.float64
+
+    def mk(op, rows, cols, pad):
+        r, c = (rows, cols) if op == "N" else (cols, rows)
+        x = ColMajor(r, c, ld=r + pad, dtype=dt)
+        v = rng.uniform(-1, 1, (c, r))
+        x.buf[:, :r] = v + 1j * rng.uniform(-1, 1, (c, r)) if cplx else v
+        x.buf[:, r:] = np.nan
+        return x
+    a, b, c = mk(op_a, m, k, 1), mk(op_b, k, n, 2), mk("N", m, n, 3)
+    c0 = c.view.copy()
+    kind = m_.complx if cplx else m_.real
+    alpha, beta = (1.25 - 0.5j, -0.75 + 0.25j) if cplx else (1.25, -0.75)
+    for be, mode_api in ((beta, "gemm_f32"), (0.0, "gemm")):
+        c.buf[:, :m] = c0.T
+        c.buf[:, m:] = np.nan
+        c._dev = None            # re-upload
+        if mode_api == "gemm_f32":
+            st = m_.gemm_f32(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, be, c.dev, c.ld, kind)
+        else:  # the same path through the mode switch
+            st = m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, be, c.dev, c.ld, "sgemm", kind)
+        import torch
+        torch.cuda.synchronize()
+        assert st == 0
+        got = c.download()
+        f32 = np.complex64 if cplx else np.float32
+        av = (a.view if op_a == "N" else a.view.T).astype(f32)
+        bv = (b.view if op_b == "N" else b.view.T).astype(f32)
+        want = f32(alpha) * (av.astype(dt) @ bv.astype(dt)) + (f32(be) * c0.astype(f32).astype(dt) if be != 0 else 0)
+        scale = np.abs(av).astype(np.float64) @ np.abs(bv).astype(np.float64) * abs(alpha) + abs(be) * np.abs(c0) + 1e-30
+        assert np.max(np.abs(got - want) / scale) < 64 * 2.0 ** -24
+        np.testing.assert_array_equal(got, got.astype(f32).astype(dt))     # values came out of an FP32 GEMM
+        assert np.isnan(c.buf[:, m:]).all()

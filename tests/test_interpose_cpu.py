@@ -1,7 +1,7 @@
 """CPU tests of the LD_PRELOAD boundary (ozimmu_amd/csrc/interpose.cpp) without a GPU.
 
 A stub `librocblas.so.5` that records calls stands in for the vendor library; a small C driver linked against
-it calls rocblas_dgemm / rocblas_gemm_ex / rocblas_dgemm_strided_batched under LD_PRELOAD=libozimmu_hip.so.
+it calls rocblas_dgemm / rocblas_gemm_ex / rocblas_{d,z}gemm_strided_batched / rocblas_gemm_strided_batched_ex under LD_PRELOAD=libozimmu_hip.so.
 Checked: the shim's definitions win symbol resolution, the pass-through reaches the vendor routine with the
 arguments untouched, and the intercept predicate (src/cublas.cu:142-148: mode, thresholds, types) decides as
 documented.  With an Ozaki mode selected and sizes above the thresholds the shim tries its own path, finds
@@ -55,6 +55,23 @@ int rocblas_dgemm_strided_batched(rocblas_handle h, int ta, int tb, int m, int n
   printf("STUB dgemm_strided_batched m=%d n=%d k=%d batch=%d\n", m, n, k, batch);
   return 0;
 }
+int rocblas_zgemm_strided_batched(rocblas_handle h, int ta, int tb, int m, int n, int k, const void* al, const void* A,
+                                  int lda, long long sa, const void* B, int ldb, long long sb, const void* be, void* C,
+                                  int ldc, long long sc, int batch) {
+  (void)h; (void)A; (void)B; (void)C; (void)al; (void)be; (void)lda; (void)ldb; (void)ldc; (void)ta; (void)tb;
+  printf("STUB zgemm_strided_batched m=%d n=%d k=%d strides=%lld,%lld,%lld batch=%d\n", m, n, k, sa, sb, sc, batch);
+  return 0;
+}
+int rocblas_gemm_strided_batched_ex(rocblas_handle h, int ta, int tb, int m, int n, int k, const void* al, const void* a,
+                                    int at, int lda, long long sa, const void* b, int bt, int ldb, long long sb,
+                                    const void* be, const void* c, int ct, int ldc, long long sc, void* d, int dt, int ldd,
+                                    long long sd, int batch, int compute, int algo, int32_t sol, uint32_t flags) {
+  (void)h; (void)al; (void)a; (void)b; (void)be; (void)c; (void)d; (void)lda; (void)ldb; (void)ldc; (void)ldd;
+  (void)algo; (void)sol; (void)flags; (void)ta; (void)tb;
+  printf("STUB gemm_strided_batched_ex m=%d n=%d k=%d types=%d,%d,%d,%d strides=%lld,%lld,%lld,%lld batch=%d compute=%d\n",
+         m, n, k, at, bt, ct, dt, sa, sb, sc, sd, batch, compute);
+  return 0;
+}
 """
 
 DRIVER_C = r"""
@@ -73,6 +90,11 @@ int rocblas_gemm_ex(rocblas_handle, int, int, int, int, int, const void*, const 
                     const void*, const void*, int, int, void*, int, int, int, int, int32_t, uint32_t);
 int rocblas_dgemm_strided_batched(rocblas_handle, int, int, int, int, int, const double*, const double*, int, long long,
                                   const double*, int, long long, const double*, double*, int, long long, int);
+int rocblas_zgemm_strided_batched(rocblas_handle, int, int, int, int, int, const void*, const void*, int, long long,
+                                  const void*, int, long long, const void*, void*, int, long long, int);
+int rocblas_gemm_strided_batched_ex(rocblas_handle, int, int, int, int, int, const void*, const void*, int, int, long long,
+                                    const void*, int, int, long long, const void*, const void*, int, int, long long, void*,
+                                    int, int, long long, int, int, int, int32_t, uint32_t);
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 64;
   int device_mode = argc > 2 ? atoi(argv[2]) : 0;
@@ -91,6 +113,13 @@ int main(int argc, char** argv) {
   printf("APP gemm_ex f32 status=%d\n", st);
   st = rocblas_dgemm_strided_batched(h, 111, 111, n, n, n, &alpha, fake, n, n * n, fake, n, n * n, &beta, fake, n, n * n, 3);
   printf("APP strided status=%d\n", st);
+  double zalpha[2] = {1.0, 0.5}, zbeta[2] = {0.0, 0.0};
+  st = rocblas_zgemm_strided_batched(h, 111, 112, n, n, n, zalpha, fake, n, n * n, fake, n, 2 * n * n, zbeta, fake, n,
+                                     3 * n * n, 2);
+  printf("APP zstrided status=%d\n", st);
+  st = rocblas_gemm_strided_batched_ex(h, 111, 111, n, n, n, &alpha, fake, 152, n, n * n, fake, 152, n, n * n, &beta, fake,
+                                       152, n, n * n, fake, 152, n, n * n, 4, 152, 0, 0, 0);
+  printf("APP strided_ex status=%d\n", st);
   rocblas_destroy_handle(h);
   return 0;
 }
@@ -137,12 +166,16 @@ EXPECT_PASSTHROUGH = textwrap.dedent("""\
     APP gemm_ex f32 status=0
     STUB dgemm_strided_batched m={n} n={n} k={n} batch=3
     APP strided status=0
+    STUB zgemm_strided_batched m={n} n={n} k={n} strides={nn},{nn2},{nn3} batch=2
+    APP zstrided status=0
+    STUB gemm_strided_batched_ex m={n} n={n} k={n} types=152,152,152,152 strides={nn},{nn},{nn},{nn} batch=4 compute=152
+    APP strided_ex status=0
     STUB destroy
     """)
 
 
 def expect(n):
-    return EXPECT_PASSTHROUGH.format(n=n, n1=n + 1, n2=n + 2)
+    return EXPECT_PASSTHROUGH.format(n=n, n1=n + 1, n2=n + 2, nn=n * n, nn2=2 * n * n, nn3=3 * n * n)
 
 
 def test_driver_without_preload(harness):
@@ -154,7 +187,14 @@ def test_preload_is_transparent_when_mode_unset_or_dgemm(harness):
     assert run(harness) == expect(64)
     assert run(harness, OZIMMU_COMPUTE_MODE="dgemm") == expect(64)
     assert run(harness, OZIMMU_COMPUTE_MODE="no_such_mode") == expect(64)
-    assert run(harness, OZIMMU_COMPUTE_MODE="sgemm") == expect(64)  # documented: FP32 emulation is out of scope
+
+
+def test_sgemm_mode_is_an_intercepting_mode(harness):
+    """src/cublas.cu:169-186: `sgemm` goes through the same predicate as the int8 modes (here: no GPU -> the handle
+    cannot be created -> logged -> forwarded to the vendor routine)"""
+    out = run(harness, OZIMMU_COMPUTE_MODE="sgemm")
+    assert "[ozIMMU ERROR]" in out
+    assert [l for l in out.splitlines() if not l.startswith("[ozIMMU")] == expect(64).splitlines()
 
 
 def test_below_threshold_passes_through_without_touching_the_gpu(harness):
