@@ -12,6 +12,10 @@ namespace ozhip {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+// cache policy of the LDS-DMA copies (cpol immediate: bit 0 sc0, bit 1 nt, bit 4 sc1); overridable for experiments
+#ifndef OZ_GLDS_AUX
+#define OZ_GLDS_AUX 0
+#endif
 #define OZ_AS1 __attribute__((address_space(1)))
 #define OZ_AS3 __attribute__((address_space(3)))
 
@@ -20,7 +24,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int VAR_ABL_MASK = 7;
 constexpr int VAR_NO_GLOBAL = 1;
 constexpr int VAR_MFMA_ONLY = 2;
-constexpr int VAR_RAND_REGS = 16384; // with VAR_MFMA_ONLY: full-entropy operands (power / clock probe)
+constexpr int VAR_REG_STAGE = 32768; // stage through registers: global_load_dwordx4 -> VGPR -> ds_write_b128 (no LDS-DMA)
+constexpr int VAR_RAND_REGS = 16384;
+constexpr int VAR_HOT = 65536; // timing probe (wrong results): every copy reads an L2-resident 1 MiB region // with VAR_MFMA_ONLY: full-entropy operands (power / clock probe)
 constexpr int VAR_GLOBAL_NO_SYNC = 3; // staging issued but never waited for / no barrier (races; timing only)
 constexpr int VAR_SYNC_NO_GLOBAL = 4; // barrier every k-step but no staging
 constexpr int VAR_GLOBAL_TO_REG = 5;  // staging loads go to registers (no LDS-DMA write), never used
@@ -147,8 +153,10 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   }
 
   // ---- staging: wave w copies row-block w of {A0, A1, B0, B1}, SL fragment blocks per k-step -------
-  const int8_t *src = (wave < WM) ? p.a_planes + (size_t)(WM * tm + wave) * p.KB * (size_t)(S * FRAG_BYTES)
-                                  : p.b_planes + (size_t)(2 * tn + (wave - WM)) * p.KB * (size_t)(S * FRAG_BYTES);
+  constexpr uint32_t RB_MASK = (VAR & VAR_HOT) ? 7u : ~0u, KB_MASK = (VAR & VAR_HOT) ? 15u : ~0u;
+  const int8_t *src = (wave < WM)
+                          ? p.a_planes + (size_t)((WM * tm + wave) & RB_MASK) * p.KB * (size_t)(S * FRAG_BYTES)
+                          : p.b_planes + (size_t)((2 * tn + (wave - WM)) & RB_MASK) * p.KB * (size_t)(S * FRAG_BYTES);
   const bool stager = wave < WM + 2; // WM = 4: waves 6,7 stage nothing
   const int8_t *src_u = src;                 // wave-uniform part (SGPRs)
   // MUBUF staging: one buffer resource per wave over ITS row-block (K/32 * S KiB, always < 4 GiB), 32-bit offsets
@@ -158,6 +166,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   src += lane * 16;
   v4i regstage[SL]; // VAR_GLOBAL_TO_REG only
   auto stage = [&](int buf, uint32_t kb) {
+    kb &= KB_MASK;
     if constexpr (ABL == VAR_GLOBAL_TO_REG) { // same HBM/L2 traffic, but no LDS write: isolates the LDS-DMA cost
       const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
 #pragma unroll
@@ -190,13 +199,13 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
         const int g0 = s / G * G;
         if (s % G == 0)
           __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + g0 * FRAG_BYTES + lane_off),
-                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 0, 0);
+                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 0, OZ_GLDS_AUX);
         else if (s % G == 1)
           __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + g0 * FRAG_BYTES + lane_off),
-                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 1024, 0);
+                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 1024, OZ_GLDS_AUX);
         else
           __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + g0 * FRAG_BYTES + lane_off),
-                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 2048, 0);
+                                           (OZ_AS3 void *)(l + g0 * FRAG_BYTES), 16, 2048, OZ_GLDS_AUX);
       }
       return;
     }
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
 #pragma unroll
     for (int s = 0; s < SL; s++)
       __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(g + s * FRAG_BYTES),
-                                       (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, 0);
+                                       (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, OZ_GLDS_AUX);
   };
 
   const int wm = wave % WM, wn = wave / WM;
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
           if (refill && stager && ABL == 0) {
             const int8_t *g = src + (size_t)(p.kb0 + k_issue) * (S * FRAG_BYTES) + i * FRAG_BYTES;
             char *l = smem + cur * STAGE_BYTES + wave * (SL * FRAG_BYTES) + i * FRAG_BYTES;
-            __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)g, (OZ_AS3 void *)l, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)g, (OZ_AS3 void *)l, 16, 0, OZ_GLDS_AUX);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -342,6 +351,55 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
       if (refill) k_issue = koff_next(k_issue);
       if (tr) trp[6] = clock64();
       if constexpr ((VAR & (VAR_SETPRIO | VAR_KICK_PRIO)) != 0) __builtin_amdgcn_s_setprio(0);
+      cur ^= 1;
+    }
+  } else if constexpr ((VAR & VAR_REG_STAGE) != 0) {
+    // ---- register-staged double buffer ---------------------------------------------------------------
+    // The loads of stage it+1 are plain global_load_dwordx4 into VGPRs, issued BEFORE the MFMAs of stage it (they
+    // cost a few issue cycles each and complete in the background); after the MFMAs the wave writes them to the
+    // other LDS buffer with ds_write_b128 and joins the single barrier of the k-step.
+    static_assert(WM == 2, "every wave stages one row-block");
+    const int8_t *gu = src_u + lane_off;
+    char *lw = smem + wave * (SL * FRAG_BYTES) + lane * 16;
+    v4i rs[SL];
+    if (nk) {
+      const int8_t *g = gu + (size_t)(p.kb0 + koff) * (S * FRAG_BYTES);
+#pragma unroll
+      for (int s = 0; s < SL; s++) rs[s] = *(const v4i *)(g + s * FRAG_BYTES);
+#pragma unroll
+      for (int s = 0; s < SL; s++) *(v4i *)(lw + s * FRAG_BYTES) = rs[s];
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < nk; it++) {
+      if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
+        __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      koff = koff + 1 == nk ? 0 : koff + 1;
+      const bool more = it + 1 < nk;
+      if (more) {
+        const int8_t *g = gu + (size_t)(p.kb0 + koff) * (S * FRAG_BYTES);
+#pragma unroll
+        for (int s = 0; s < SL; s++) rs[s] = *(const v4i *)(g + s * FRAG_BYTES);
+      }
+      const char *la = smem + cur * STAGE_BYTES + wm * (SL * FRAG_BYTES) + lane * 16;
+      const char *lb = smem + cur * STAGE_BYTES + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
+      v4i bf[SL];
+#pragma unroll
+      for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb + j * FRAG_BYTES);
+#pragma unroll
+      for (int i = 0; i < SL; i++) {
+        const v4i af = *(const v4i *)(la + i * FRAG_BYTES);
+#pragma unroll
+        for (int j = 0; j < SL; j++) {
+          const int d = i + j;
+          if (d >= D0 && d < D0 + ND && d <= S - 1)
+            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af, acc[d - D0], 0, 0, 0);
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int s = 0; s < SL; s++) *(v4i *)(lw + (cur ^ 1) * STAGE_BYTES + s * FRAG_BYTES) = rs[s];
+      }
+      __syncthreads();
       cur ^= 1;
     }
   } else {

@@ -24,7 +24,7 @@ using namespace ozhip;
     }                                                                              \
   } while (0)
 
-__global__ void fill_planes(int8_t *p, size_t n, unsigned seed) {
+__global__ void fill_planes(int8_t *p, size_t n, unsigned seed, unsigned mask) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -32,7 +32,7 @@ __global__ void fill_planes(int8_t *p, size_t n, unsigned seed) {
     x ^= x >> 15;
     x *= 2246822519u;
     x ^= x >> 13;
-    int v = (int)(x & 127u);
+    int v = (int)(x & mask); // mask 127: full-entropy slices; 1: low-toggle data (power probe)
     if (x & 0x100u) v = -v;
     p[i] = (int8_t)v;
   }
@@ -61,7 +61,7 @@ static float run(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEven
 
 template <int S, int VAR>
 static float run_pp(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  constexpr size_t lds = 2 * 6 * S * FRAG_BYTES;
+  constexpr size_t lds = 2 * 6 * S * FRAG_BYTES + ((VAR & 1) ? 8192 : 0);
   SliceGemmArgs a = a0;
   a.tiles_m = (a.M + 63) / 64;
   a.tiles_n = (a.N + 127) / 128;
@@ -96,8 +96,9 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&eb, 8 * N));
   CK(hipMalloc(&C, 8 * M * N));
   CK(hipMalloc(&phase, 8 * 256));
-  hipLaunchKernelGGL(fill_planes, dim3(4096), dim3(256), 0, 0, A, pa, 1u);
-  hipLaunchKernelGGL(fill_planes, dim3(4096), dim3(256), 0, 0, B, pb, 2u);
+  const unsigned mask = argc > 3 ? (unsigned)std::atoi(argv[3]) : 127u;
+  hipLaunchKernelGGL(fill_planes, dim3(4096), dim3(256), 0, 0, A, pa, 1u, mask);
+  hipLaunchKernelGGL(fill_planes, dim3(4096), dim3(256), 0, 0, B, pb, 2u, mask);
   std::vector<double> ones(std::max(M, N), 1.0);
   CK(hipMemcpy(ea, ones.data(), 8 * M, hipMemcpyHostToDevice));
   CK(hipMemcpy(eb, ones.data(), 8 * N, hipMemcpyHostToDevice));
@@ -138,6 +139,8 @@ int main(int argc, char **argv) {
   std::vector<Var> vars = {
       {"shipped 64x64", run<S, VAR_SHIPPED>, false, {}},
       {"ping-pong 64x128", run_pp<S, 0>, false, {}},
+      {"ping-pong 64x128 MUBUF", run_pp<S, 2>, false, {}},
+      {"shipped, L2-hot addresses", run<S, VAR_SHIPPED | VAR_HOT>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
       {"mfma-only low-entropy regs", run<S, VAR_MFMA_ONLY>, false, {}},
       {"mfma-only random regs", run<S, VAR_MFMA_ONLY | VAR_RAND_REGS>, false, {}},
@@ -156,12 +159,45 @@ int main(int argc, char **argv) {
       CK(hipMemset(C, 0xFF, 8 * M * N));
       if (which == 0) run<S, VAR_SHIPPED>(a, st, e0, e1);
       if (which == 1) run_pp<S, 0>(a, st, e0, e1);
-      if (which == 2) run<S, VAR_SHIPPED | VAR_INTERLEAVE, 4>(a, st, e0, e1);
+      if (which == 2) run_pp<S, 2>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
       for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
       std::printf("check variant %d vs plain loop: %zu mismatching elements of %zu\n", which, bad, M * N);
     }
+  }
+  for (int which = 0; which < 2; which++) { // per-phase trace of the ping-pong kernel: first round, mid-kernel
+    unsigned long long *tr;
+    const size_t ntr = 64 * 8 * 16 * 8;
+    CK(hipMalloc(&tr, ntr * 8));
+    CK(hipMemset(tr, 0, ntr * 8));
+    SliceGemmArgs b = a;
+    b.trace = tr;
+    b.trace_block0 = which ? 4096 : 0;
+    run_pp<S, 3>(b, st, e0, e1);
+    std::vector<unsigned long long> h(ntr);
+    CK(hipMemcpy(h.data(), tr, ntr * 8, hipMemcpyDeviceToHost));
+    const char *names[2][7] = {{"45 MFMA", "wait vmcnt", "barrier", "copy issue", "frag reads", "wait lgkm", "barrier"},
+                               {"copy issue", "frag reads", "wait lgkm", "barrier", "45 MFMA", "wait vmcnt", "barrier"}};
+    for (int g = 0; g < 2; g++) {
+      double sum[7] = {0}, tot = 0;
+      int cnt = 0;
+      for (int blk = 0; blk < 64; blk++)
+        for (int w = 4 * g; w < 4 * g + 4; w++)
+          for (int it = 0; it < 15; it++) {
+            const unsigned long long *t = &h[((size_t)(blk * 8 + w) * 16 + it) * 8];
+            const unsigned long long *tn = t + 8;
+            if (!t[0] || !tn[0]) continue;
+            for (int k = 0; k < 6; k++) sum[k] += (double)(t[k + 1] - t[k]);
+            sum[6] += (double)(tn[0] - t[6]);
+            tot += (double)(tn[0] - t[0]);
+            cnt++;
+          }
+      std::printf("pp trace G%d, workgroups %u..: %.0f ticks per k-step (%d samples):", g, b.trace_block0, tot / cnt, cnt);
+      for (int k = 0; k < 7; k++) std::printf("  %s %.0f", names[g][k], sum[k] / cnt);
+      std::printf("\n");
+    }
+    CK(hipFree(tr));
   }
   const double ops = 45.0 * 2.0 * M * N * K;
   std::printf("N=%zu S=%d rounds=%d  (TOPS = 45*2*N^3 / t)\n", N, S, rounds);

@@ -27,6 +27,7 @@ namespace ozhip {
 
 template <int S, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void slice_gemm_pp_kernel(const SliceGemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__) // the host pass only needs the stub (arrays of buffer resources do not parse there)
   constexpr int SL = S, ND = S, D0 = 0;
   constexpr int STAGE_BYTES = 6 * SL * FRAG_BYTES; // slots: A0 A1 B0 B1 B2 B3
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,9 +71,23 @@ __global__ __launch_bounds__(512, 2) void slice_gemm_pp_kernel(const SliceGemmAr
   const int8_t *sh_src[NSH];
 #pragma unroll
   for (int i = 0; i < NSH; i++) sh_src[i] = block_src(3 * S * g + (w + 4 * i < 3 * S ? w + 4 * i : 0));
+  // VAR & 2: MUBUF form of the copies (one buffer resource per share block over its row-block, always < 4 GiB):
+  // SGPR resource + ONE lane-offset VGPR + SGPR byte offset -- cheaper to issue under MFMA load
+  __amdgpu_buffer_rsrc_t sh_rsrc[NSH];
+#pragma unroll
+  for (int i = 0; i < NSH; i++)
+    sh_rsrc[i] = __builtin_amdgcn_make_buffer_rsrc((void *)sh_src[i], 0, (int)(p.KB * (uint32_t)(S * FRAG_BYTES)), 0x00020000);
+  auto copy_share = [&](int i, uint32_t kb, int buf, int qg) {
+    if constexpr ((VAR & 2) != 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sh_rsrc[i], (OZ_AS3 void *)(smem + buf * STAGE_BYTES + qg * FRAG_BYTES), 16,
+                                               lane_off, kb * (uint32_t)(S * FRAG_BYTES), 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(sh_src[i] + (size_t)kb * (S * FRAG_BYTES) + lane_off),
+                                       (OZ_AS3 void *)(smem + buf * STAGE_BYTES + qg * FRAG_BYTES), 16, 0, OZ_GLDS_AUX);
+  };
   auto copy_block = [&](const int8_t *gsrc, uint32_t kb, int buf, int qg) {
     __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gsrc + (size_t)kb * (S * FRAG_BYTES) + lane_off),
-                                     (OZ_AS3 void *)(smem + buf * STAGE_BYTES + qg * FRAG_BYTES), 16, 0, 0);
+                                     (OZ_AS3 void *)(smem + buf * STAGE_BYTES + qg * FRAG_BYTES), 16, 0, OZ_GLDS_AUX);
   };
 
   v16i acc[ND];
@@ -140,45 +155,75 @@ __global__ __launch_bounds__(512, 2) void slice_gemm_pp_kernel(const SliceGemmAr
       half_barrier();
       for (uint32_t t = 0; t < nk; t++) {
         const int cur = t & 1;
+        const bool tr = (VAR & 1) != 0 && p.trace && t >= 64 && t < 80 && lane == 0 && blockIdx.x - p.trace_block0 < 64;
+        // stamps go to spare LDS (a global store would sit in vmcnt and distort the waits) and are dumped at the end
+        unsigned long long *trp = (unsigned long long *)(smem + 2 * STAGE_BYTES) + (size_t)(wave * 16 + (t & 15)) * 8;
+        if (tr) trp[0] = clock64();
         compute();                                       // half-step 2t: k-step t
+        if (tr) trp[1] = clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // my copies of stage t+1 (issued one half-step ago) landed
         publish(t);
+        if (tr) trp[2] = clock64();
         half_barrier();
-        if (t + 1 < nk) read_frags(cur ^ 1); // half-step 2t+1: fragments of k-step t+1, and
-        if (t + 2 < nk) {                    // A0 A1 B0 of stage t+2 into the buffer stage t just left
+        if (tr) trp[3] = clock64();
+        // half-step 2t+1: first the copies (A0 A1 B0 of stage t+2 into the buffer stage t just left) so that they
+        // get the whole half-step plus the next compute phase to land, then the fragments of k-step t+1
+        if (t + 2 < nk) {
           const uint32_t kb2 = kblock(t + 2);
 #pragma unroll
           for (int i = 0; i < NSH; i++)
-            if (w + 4 * i < 3 * S) copy_block(sh_src[i], kb2, cur, w + 4 * i);
+            if (w + 4 * i < 3 * S) copy_share(i, kb2, cur, w + 4 * i);
         }
+        if (tr) trp[4] = clock64();
+        if (t + 1 < nk) read_frags(cur ^ 1);
+        if (tr) trp[5] = clock64();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tr) trp[6] = clock64();
         half_barrier();
       }
     } else {
       half_barrier(); // half-step -1: nothing to do
       for (uint32_t t = 0; t < nk; t++) {
         const int cur = t & 1;
-        read_frags(cur); // half-step 2t: fragments of k-step t, and
+        const bool tr = (VAR & 1) != 0 && p.trace && t >= 64 && t < 80 && lane == 0 && blockIdx.x - p.trace_block0 < 64;
+        // stamps go to spare LDS (a global store would sit in vmcnt and distort the waits) and are dumped at the end
+        unsigned long long *trp = (unsigned long long *)(smem + 2 * STAGE_BYTES) + (size_t)(wave * 16 + (t & 15)) * 8;
+        if (tr) trp[0] = clock64();
+        // half-step 2t: copies first (see G0), then the fragments of k-step t
         const uint32_t kb1 = kblock(t + 1), kb2 = kblock(t + 2);
 #pragma unroll
         for (int i = 0; i < NSH; i++) {
           const int q = w + 4 * i;
           if (q < S) { // B1 of stage t+2 (G0 read B1 of stage t one half-step ago)
-            if (t + 2 < nk) copy_block(sh_src[i], kb2, cur, 3 * S + q);
+            if (t + 2 < nk) copy_share(i, kb2, cur, 3 * S + q);
           } else if (q < 3 * S) { // B2, B3 of stage t+1
-            if (t + 1 < nk) copy_block(sh_src[i], kb1, cur ^ 1, 3 * S + q);
+            if (t + 1 < nk) copy_share(i, kb1, cur ^ 1, 3 * S + q);
           }
         }
+        if (tr) trp[1] = clock64();
+        read_frags(cur);
+        if (tr) trp[2] = clock64();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tr) trp[3] = clock64();
         half_barrier();
+        if (tr) trp[4] = clock64();
         compute(); // half-step 2t+1: k-step t
+        if (tr) trp[5] = clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tr) trp[6] = clock64();
         half_barrier();
       }
     }
   }
 
+  if constexpr ((VAR & 1) != 0) {
+    __syncthreads();
+    if (p.trace && blockIdx.x - p.trace_block0 < 64 && nk >= 80)
+      for (int i = threadIdx.x; i < 8 * 16 * 8; i += 512)
+        p.trace[(size_t)(blockIdx.x - p.trace_block0) * (8 * 16 * 8) + i] = ((unsigned long long *)(smem + 2 * STAGE_BYTES))[i];
+  }
   recombine_and_store<D0, ND>(p, acc, tm * 64 + wm * 32 + (lane & 31), tn * 128 + g * 64 + wn * 32 + 4 * (lane >> 5));
+#endif
 }
 
 } // namespace ozhip
