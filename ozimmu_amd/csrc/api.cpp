@@ -97,6 +97,12 @@ static Workspace carve(void *base, size_t m, size_t n, size_t k, int S, bool nee
   return w;
 }
 
+// lead throttle of the fused kernel (slice_gemm_kernel.h): only long-K, many-tile problems drift enough to gain
+static uint32_t throttle_for(size_t m, size_t n, size_t k) {
+  if (env_enabled("OZIMMU_HIP_NO_THROTTLE", false)) return 0u;
+  return (k >= 6144 && ((m + 63) / 64) * ((n + 63) / 64) >= 2048) ? 1u : 0u;
+}
+
 static bool needs_acc(size_t k, int S) {
   const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k);
   return S > SINGLE_PASS_MAX_S || k > max_k_per_pass(S, L);
@@ -184,6 +190,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   g.ldc = ldc;
   g.acc = w.acc;
   g.phase = env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) ? nullptr : w.phase;
+  g.throttle = throttle_for(m, n, k);
   g.dump = dump;
   g.dump_only = dump ? 1 : 0;
   const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
@@ -299,6 +306,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     g.ldc = ldc;
     g.acc = w.acc;
     g.phase = env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) ? nullptr : w.phase;
+    g.throttle = throttle_for(m, n, k);
     const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
     for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
       g.kb0 = kb0;

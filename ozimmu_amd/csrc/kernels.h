@@ -28,6 +28,7 @@ struct SliceGemmArgs {
   int acc_in;  // start the fma chain from acc instead of 0
   int final;   // 1: scale + alpha/beta -> C; 0: -> acc
   uint32_t *phase; // 8 advisory words (one per XCD): k-block the XCD's workgroups are at; zeroed per call
+  uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue
   unsigned long long *trace; // development only (tools/gemm_ablate.hip, VAR_TRACE)

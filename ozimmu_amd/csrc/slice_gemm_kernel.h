@@ -13,6 +13,15 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 // cache policy of the LDS-DMA copies (cpol immediate: bit 0 sc0, bit 1 nt, bit 4 sc1); overridable for experiments
+#ifndef OZ_THR_MASK // lead-throttle parameters (VAR_THROTTLE)
+#define OZ_THR_MASK 15u
+#endif
+#ifndef OZ_THR_LEAD
+#define OZ_THR_LEAD 2u
+#endif
+#ifndef OZ_THR_MAXU
+#define OZ_THR_MAXU 8u
+#endif
 #ifndef OZ_GLDS_AUX
 #define OZ_GLDS_AUX 0
 #endif
@@ -299,6 +308,15 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (tr) trp[1] = clock64();
+      uint32_t hint = 0;
+      // Lead throttle.  Workgroups of an XCD share A/B panels through its L2 only while they are within the L2's
+      // retention window of each other (~14 k-steps of patch traffic); they start aligned (phase hint) but drift.
+      // Every 16th k-step wave 0 samples the phase word (scalar load, consumed after the lgkmcnt(0) below) and, if
+      // this workgroup is more than 2 k-steps ahead of the last publisher, sleeps before releasing the barrier:
+      // leaders wait for the pack instead of missing in L2.  Pays off for long K (drift grows with the number of
+      // k-steps): +1..4 % at 8192^3 / 16384^3, neutral below; the host enables it for K >= 6144 only.
+      const bool probe = p.throttle && phase && wave == 0 && (it & OZ_THR_MASK) == 1u;
+      if (probe) asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(hint) : "s"(phase) : "memory");
       __builtin_amdgcn_s_barrier(); // stage `it` is in LDS for every wave
       asm volatile("" ::: "memory");
       if (tr) trp[2] = clock64();
@@ -309,6 +327,21 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
       for (int i = 0; i < SL; i++) af[i] = *(const v4i *)(la0 + cur * STAGE_BYTES + i * FRAG_BYTES);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (tr) trp[3] = clock64();
+      if (probe) {
+        asm volatile("" : "+s"(hint)); // the scalar load has landed (lgkmcnt(0) above)
+        const uint32_t lead = koff >= hint ? koff - hint : koff + nk - hint; // k-steps ahead of the last publisher
+        if (lead > OZ_THR_LEAD && lead < (nk >> 1)) {
+          // ~one k-step (P MFMAs of 32 cycles x two workgroups per SIMD) per k-step of excess lead, at most 8
+          const uint32_t units = lead - OZ_THR_LEAD < OZ_THR_MAXU ? lead - OZ_THR_LEAD : OZ_THR_MAXU;
+          constexpr uint32_t PER_UNIT = []() { // MFMAs per k-step of this instance, x 64 cycles
+            uint32_t c = 0;
+            for (int i = 0; i < SL; i++)
+              for (int j = 0; j < SL; j++) c += (i + j >= D0 && i + j < D0 + ND && i + j <= S - 1) ? 1u : 0u;
+            return c;
+          }();
+          for (uint32_t u = 0; u < units * PER_UNIT; u++) __builtin_amdgcn_s_sleep(1);
+        }
+      }
       __builtin_amdgcn_s_barrier(); // every wave holds its fragments: buffer `cur` is free
       asm volatile("" ::: "memory");
       if (tr) trp[4] = clock64();

@@ -60,6 +60,13 @@ static float run(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEven
 }
 
 template <int S, int VAR>
+static float run_throttled(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  SliceGemmArgs a = a0;
+  a.throttle = 1;
+  return run<S, VAR>(a, st, e0, e1);
+}
+
+template <int S, int VAR>
 static float run_pp(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   constexpr size_t lds = 2 * 6 * S * FRAG_BYTES + ((VAR & 1) ? 8192 : 0);
   SliceGemmArgs a = a0;
@@ -140,6 +147,7 @@ int main(int argc, char **argv) {
       {"shipped 64x64", run<S, VAR_SHIPPED>, false, {}},
       {"ping-pong 64x128", run_pp<S, 0>, false, {}},
       {"ping-pong 64x128 MUBUF", run_pp<S, 2>, false, {}},
+      {"shipped + lead throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
       {"shipped, L2-hot addresses", run<S, VAR_SHIPPED | VAR_HOT>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
       {"mfma-only low-entropy regs", run<S, VAR_MFMA_ONLY>, false, {}},
@@ -159,7 +167,7 @@ int main(int argc, char **argv) {
       CK(hipMemset(C, 0xFF, 8 * M * N));
       if (which == 0) run<S, VAR_SHIPPED>(a, st, e0, e1);
       if (which == 1) run_pp<S, 0>(a, st, e0, e1);
-      if (which == 2) run_pp<S, 2>(a, st, e0, e1);
+      if (which == 2) run_throttled<S, VAR_SHIPPED>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
       for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];

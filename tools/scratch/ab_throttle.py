@@ -1,0 +1,29 @@
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create()
+oz.set_cuda_stream(h, torch.cuda.current_stream())
+def bench(m, n, k, mode, opa="N", opb="N", reps=6):
+    a = torch.rand((k, m) if opa == "N" else (m, k), dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand((n, k) if opb == "N" else (k, n), dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(n, m, dtype=torch.float64, device="cuda")
+    lda, ldb = a.shape[1], b.shape[1]
+    out = {}
+    for rnd in range(2):
+        for thr in ("0", "1"):
+            os.environ["OZIMMU_HIP_NO_THROTTLE"] = thr
+            for _ in range(2): oz.gemm(h, opa, opb, m, n, k, 1.0, a, lda, b, ldb, 0.0, c, m, mode)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps): oz.gemm(h, opa, opb, m, n, k, 1.0, a, lda, b, ldb, 0.0, c, m, mode)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+            out[thr] = min(out.get(thr, 1e9), dt)
+    tf = lambda t: 2.0 * m * n * k / t / 1e12
+    print(f"{mode:14s} m={m} n={n} k={k} {opa}{opb}: throttle {tf(out['0']):6.1f} TF   off {tf(out['1']):6.1f} TF   ({(out['1']/out['0']-1)*100:+.1f} %)", flush=True)
+pass
+for n in (8192,): bench(n, n, n, "fp64_int8_9")
+bench(8192, 8192, 8192, "fp64_int8_8")
+bench(8192, 8192, 8192, "fp64_int8_12", reps=3)
+bench(8192, 8192, 8192, "fp64_int8_14", reps=3)
+bench(32768, 32768, 1024, "fp64_int8_9", "N", "T", reps=3)
+bench(16384, 16384, 16384, "fp64_int8_9", reps=2)
+oz.destroy(h)
