@@ -35,6 +35,7 @@ constexpr int VAR_NO_GLOBAL = 1;
 constexpr int VAR_MFMA_ONLY = 2;
 constexpr int VAR_REG_STAGE = 32768; // stage through registers: global_load_dwordx4 -> VGPR -> ds_write_b128 (no LDS-DMA)
 constexpr int VAR_RAND_REGS = 16384;
+constexpr int VAR_HOT1 = 131072; // timing probe (wrong results): every copy of a wave re-reads ONE 1 KiB block (L1 hits)
 constexpr int VAR_HOT = 65536; // timing probe (wrong results): every copy reads an L2-resident 1 MiB region // with VAR_MFMA_ONLY: full-entropy operands (power / clock probe)
 constexpr int VAR_GLOBAL_NO_SYNC = 3; // staging issued but never waited for / no barrier (races; timing only)
 constexpr int VAR_SYNC_NO_GLOBAL = 4; // barrier every k-step but no staging
@@ -187,6 +188,12 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     if constexpr (ABL != 0 && ABL != VAR_GLOBAL_NO_SYNC) return;
     if (!stager) return;
     char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
+    if constexpr ((VAR & VAR_HOT1) != 0) {
+#pragma unroll
+      for (int s = 0; s < SL; s++)
+        __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)src, (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, 0);
+      return;
+    }
     if constexpr ((VAR & VAR_MUBUF) != 0) {
       // MUBUF form (buffer_load ... lds): SGPR resource + ONE lane-offset VGPR + SGPR byte offset.  Under MFMA load a
       // wave issues these in ~60 cycles each, against ~140 for global_load_lds with a 64-bit VGPR address pair

@@ -149,6 +149,7 @@ int main(int argc, char **argv) {
       {"ping-pong 64x128 MUBUF", run_pp<S, 2>, false, {}},
       {"shipped + lead throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
       {"shipped, L2-hot addresses", run<S, VAR_SHIPPED | VAR_HOT>, false, {}},
+      {"shipped, L1-hot addresses", run<S, VAR_SHIPPED | VAR_HOT1>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
       {"mfma-only low-entropy regs", run<S, VAR_MFMA_ONLY>, false, {}},
       {"mfma-only random regs", run<S, VAR_MFMA_ONLY | VAR_RAND_REGS>, false, {}},
