@@ -148,6 +148,8 @@ int main(int argc, char **argv) {
       {"ping-pong 64x128", run_pp<S, 0>, false, {}},
       {"ping-pong 64x128 MUBUF", run_pp<S, 2>, false, {}},
       {"shipped + lead throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
+      {"MUBUF copies", run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>, false, {}},
+      {"MUBUF copies + throttle", run_throttled<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>, false, {}},
       {"shipped, L2-hot addresses", run<S, VAR_SHIPPED | VAR_HOT>, false, {}},
       {"shipped, L1-hot addresses", run<S, VAR_SHIPPED | VAR_HOT1>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
