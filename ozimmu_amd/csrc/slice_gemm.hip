@@ -26,13 +26,13 @@
 
 namespace ozhip {
 
-template <int S, int D0, int ND>
+template <int S, int D0, int ND, int FORCE_WM = 0>
 static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
-  // Workgroup shape.  Up to 10 staged slices: 4 waves / 64x64, two workgroups per CU (they cover each other's
+  // Workgroup shape (FORCE_WM: the caller's choice, see launch_S).  Up to 10 staged slices: 4 waves / 64x64, two workgroups per CU (they cover each other's
   // LDS-read phases).  11..13 staged slices do not fit twice in 160 KiB of LDS: one 8-wave 128x64 workgroup per CU
   // (2*(4+2)*SL KiB).  More than 13 (second pass of S >= 14): back to 64x64, one workgroup per CU.
-  constexpr int WM = (SL >= 11 && SL <= 13) ? 4 : 2;
+  constexpr int WM = FORCE_WM ? FORCE_WM : ((SL >= 11 && SL <= 13) ? 4 : 2);
   constexpr size_t lds = 2 * (WM + 2) * SL * FRAG_BYTES;
   // the prefetch-2 loop keeps all 2*SL fragments in registers next to the 16*ND accumulators: beyond
   // ~232 of the 256 VGPRs (2 waves/SIMD) it would spill inside the k loop, and with one 8-wave workgroup per CU
@@ -59,6 +59,11 @@ static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
 template <int S>
 static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
   if constexpr (S <= SINGLE_PASS_MAX_S) {
+    if constexpr (S <= 6) {
+      // few slices = few MFMAs per staged byte: the 128x64 8-wave workgroup (-25 % staged bytes) wins once there
+      // are enough tiles to fill the chip (4096^3: S=3 +8 %, S=4 +18 %, S=5 +10 %, S=6 +7 %; S=7 +1 %, S=8 -2 %)
+      if ((size_t)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 512) return launch_one<S, 0, S, 4>(a, stream);
+    }
     return launch_one<S, 0, S>(a, stream);
   } else {
     constexpr int ND1 = (S + 1) / 2, ND2 = S - ND1;

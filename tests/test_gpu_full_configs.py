@@ -132,3 +132,27 @@ def test_c5_hpl_panel_32768_k1024_nt(oz):
     C2 = C.clone()
     _gemm(m_, h, "N", "T", m, n, k, A, B, C2, "fp64_int8_9", alpha=0.5, beta=2.0)
     assert torch.equal(C2, 2.5 * C)                        # powers of two and 2.5x: fma(0.5, x, 2x) == 2.5x exactly
+
+
+@pytest.mark.parametrize("S", [3, 4, 6, 9, 12])
+def test_sub_block_consistency_across_tile_shapes(oz, S):
+    """An element of C depends only on its row of op(A) and its column of op(B): computing a column block of C in a
+    separate, smaller call must give the same bits.  The full call (4096 x 8192 outputs) and the block calls
+    (4096 x 448 and 200 x 8192) are scheduled differently -- other workgroup shape (128x64 vs 64x64 for S <= 6),
+    other tile order, other k rotation -- so this pins the launch policy to the arithmetic."""
+    import torch
+    m_, h = oz
+    m, n, k = 4096, 8192, 288
+    A = _dev_rand((m, k), 11, -4.0, 4.0)            # op T: stored k-contiguous, (rows, ld=k)
+    B = _dev_rand((n, k), 12)                       # op N: (cols, ld=k)
+    mode = f"fp64_int8_{S}"
+    C = torch.empty((n, m), dtype=torch.float64, device="cuda")
+    _gemm(m_, h, "T", "N", m, n, k, A, B, C, mode)
+    j0, nb = 1000, 448                               # a column block of C
+    Cb = torch.empty((nb, m), dtype=torch.float64, device="cuda")
+    _gemm(m_, h, "T", "N", m, nb, k, A, B[j0:j0 + nb], Cb, mode)
+    assert torch.equal(Cb, C[j0:j0 + nb])
+    i0, mb = 3000, 200                               # a row block of C
+    Cr = torch.empty((n, mb), dtype=torch.float64, device="cuda")
+    _gemm(m_, h, "T", "N", mb, n, k, A[i0:i0 + mb], B, Cr, mode)
+    assert torch.equal(Cr, C[:, i0:i0 + mb])
