@@ -38,7 +38,7 @@ static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   // ~232 of the 256 VGPRs (2 waves/SIMD) it would spill inside the k loop, and with one 8-wave workgroup per CU
   // its LDS read burst is exposed (tools/gemm_ablate.hip: 24.3 vs 19.6 ms): those cases stream the A fragments
   // (prefetch distance 1).
-  constexpr int VAR_PRODUCTION = (WM == 2 && 16 * ND + 8 * SL <= 232) ? VAR_SHIPPED : (VAR_SHIPPED & ~VAR_PF2);
+  constexpr int VAR_PRODUCTION = (WM == 2 && 16 * ND + 8 * SL <= 240) ? VAR_SHIPPED : (VAR_SHIPPED & ~VAR_PF2);
   SliceGemmArgs a = a0;
   a.tiles_m = (a.M + 32 * WM - 1) / (32 * WM);
   a.tiles_n = (a.N + 63) / 64;
