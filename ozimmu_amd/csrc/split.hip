@@ -122,114 +122,165 @@ hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t 
 
 // ---- shared: load one 32 rows x 32 k block, lane (r = lane&31, kh = lane>>5) gets its 16 k values ---
 // Out-of-range rows / k read as +0.0 (-> zero slices: the padding the GEMM relies on).
+// Two steps so that a wave can have the NEXT block's loads in flight while it cuts the current one:
+//   fetch_block      global -> registers, coalesced in both layouts (half-wave = 32 consecutive doubles)
+//   arrange_block    row-contiguous: already in place; k-contiguous: transpose through the wave's LDS tile
 template <bool KCONTIG>
-__device__ __forceinline__ void load_block(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
-                                           size_t rb, size_t kb, int lane, double (*tile)[33],
-                                           double v[16]) {
-  const int r = lane & 31, kh = lane >> 5;
+__device__ __forceinline__ void fetch_block(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
+                                            size_t rb, size_t kb, int lane, double t[16]) {
   if constexpr (!KCONTIG) {
-    const size_t rg = rb * 32 + r;
-    const size_t kbase = kb * 32 + kh * 16;
+    const size_t rg = rb * 32 + (lane & 31);
+    const size_t kbase = kb * 32 + (lane >> 5) * 16;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const size_t k = kbase + q;
-      v[q] = (rg < rows && k < K) ? in[k * sk + rg * sr] : 0.0;
+      t[q] = (rg < rows && k < K) ? in[k * sk + rg * sr] : 0.0;
     }
   } else {
-    // coalesced read: half-wave = 32 consecutive k of one row; 2 rows per instruction
     const size_t k = kb * 32 + (lane & 31);
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int rr = it * 2 + (lane >> 5);
-      const size_t rg = rb * 32 + rr;
-      tile[rr][lane & 31] = (rg < rows && k < K) ? in[rg * sr + k * sk] : 0.0;
+    for (int it = 0; it < 16; it++) { // 2 rows per instruction
+      const size_t rg = rb * 32 + it * 2 + (lane >> 5);
+      t[it] = (rg < rows && k < K) ? in[rg * sr + k * sk] : 0.0;
     }
+  }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void arrange_block(const double t[16], int lane, double (*tile)[33], double v[16]) {
+  if constexpr (!KCONTIG) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = t[q];
+  } else {
+    __builtin_amdgcn_wave_barrier(); // the previous block's reads of the tile are done
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 16; it++) tile[it * 2 + (lane >> 5)][lane & 31] = t[it];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int r = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = tile[r][kh * 16 + q];
   }
 }
 
-// ---- pass 2: cut ---------------------------------------------------------------------------------------
 template <bool KCONTIG>
+__device__ __forceinline__ void load_block(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
+                                           size_t rb, size_t kb, int lane, double (*tile)[33], double v[16]) {
+  double t[16];
+  fetch_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, t);
+  arrange_block<KCONTIG>(t, lane, tile, v);
+}
+
+// ---- pass 2: cut ---------------------------------------------------------------------------------------
+// One wave cuts `strip` consecutive blocks along the memory-contiguous axis of the operand.  k-contiguous operands
+// (PREFETCH): the loads of the next block are issued before the current one is cut -- with the LDS transpose the
+// kernel sits at 2 waves/SIMD, too few to hide HBM latency by occupancy alone (8192^2: 0.53 -> 0.31 ms).
+// Row-contiguous operands keep one block per wave at 3 waves/SIMD (prefetching there only costs registers).
+template <bool KCONTIG, bool PREFETCH = KCONTIG>
 __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in, size_t rows, size_t K,
                                                   size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
                                                   int8_t *__restrict__ planes, double *__restrict__ max_exp,
-                                                  size_t RB, size_t KB) {
+                                                  size_t RB, size_t KB, int strip) {
   __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int CUT_STRIP = PREFETCH ? strip : 1;
+  // strips along the contiguous axis: k-contiguous -> CUT_STRIP k-blocks of one row-block, else CUT_STRIP row-blocks
+  const size_t strips_fast = ((KCONTIG ? KB : RB) + CUT_STRIP - 1) / CUT_STRIP;
   const size_t gw = (size_t)blockIdx.x * 4 + wave;
-  if (gw >= RB * KB) return;
-  // consecutive waves follow the memory-contiguous axis of the operand
-  const size_t rb = KCONTIG ? gw / KB : gw % RB;
-  const size_t kb = KCONTIG ? gw % KB : gw / RB;
+  if (gw >= strips_fast * (KCONTIG ? RB : KB)) return;
+  const size_t slow = gw / strips_fast, fast0 = (gw % strips_fast) * CUT_STRIP;
+  const size_t nfast = KCONTIG ? KB : RB;
+  auto block_of = [&](int b, size_t &rb, size_t &kb) {
+    rb = KCONTIG ? slow : fast0 + b;
+    kb = KCONTIG ? fast0 + b : slow;
+  };
 
-  double v[16];
-  load_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
-
-  const int r = lane & 31;
-  const size_t rg = rb * 32 + r;
-  const unsigned e = rg < rows ? exps[rg] : 0u;
-  // e == 0: zero/subnormal row -> max_exp 0, zero slices (reference: 0*2 = 0, src/split.cu:191)
-  // e >= 0x7FE: Inf/NaN in the row, or 2^(e+1) not representable -> poisoned row (max_exp = NaN)
-  const bool live = e != 0u && e < 0x7FEu;
-  if (kb == 0 && lane < 32 && rg < rows) {
-    const unsigned long long bits =
-        live ? ((unsigned long long)(e + 1) << 52) : (e == 0u ? 0ull : 0x7FF8000000000000ull);
-    max_exp[rg] = __longlong_as_double((long long)bits);
+  double t[16];
+  if constexpr (PREFETCH) {
+    size_t rb, kb;
+    block_of(0, rb, kb);
+    fetch_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, t);
   }
-
-  // 128-bit shifted mantissa (hi:lo) = (m53 << 75) >> off, per element (src/split.cu:163-175)
-  unsigned long long hi[16], lo[16];
-  unsigned negmask[4] = {0, 0, 0, 0}; // per packed word: 0xFF in the bytes of negative elements
-#pragma unroll
-  for (int q = 0; q < 16; q++) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v[q]);
-    const unsigned f = (unsigned)(b >> 52) & 0x7FFu;
-    const unsigned long long m53 = (b & MANT_MASK) | (f ? (1ull << 52) : 0ull);
-    const unsigned ef = f ? f : 1u; // subnormal: exponent of field 1 (fix of SURVEY §8a quirk 7)
-    const unsigned off = e + 1u - ef; // >= 1 for live rows
-    const unsigned long long V = live ? (m53 << 11) : 0ull;
-    unsigned long long h, l;
-    if (off < 64u) {
-      h = V >> off;
-      l = V << (64u - off); // off >= 1
-    } else if (off < 128u) {
-      h = 0;
-      l = V >> (off - 64u);
+#pragma unroll 1
+  for (int b = 0; b < CUT_STRIP && fast0 + b < nfast; b++) {
+    size_t rb, kb;
+    block_of(b, rb, kb);
+    double v[16];
+    if constexpr (PREFETCH) {
+      arrange_block<KCONTIG>(t, lane, tiles[KCONTIG ? wave : 0], v);
+      if (b + 1 < CUT_STRIP && fast0 + b + 1 < nfast) { // next block's loads fly while this one is cut
+        size_t rbn, kbn;
+        block_of(b + 1, rbn, kbn);
+        fetch_block<KCONTIG>(in, rows, K, sr, sk, rbn, kbn, lane, t);
+      }
     } else {
-      h = 0;
-      l = 0;
+      load_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
     }
-    hi[q] = h;
-    lo[q] = l;
-    if (b >> 63) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
-  }
 
-  const unsigned long long mask = (1ull << L) - 1ull;
-  int8_t *out = planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16;
-  for (int s = 0; s < S; s++) {
-    const int p = 128 - (s + 1) * L; // low bit of slice s inside (hi:lo); p >= 2 since S*L <= 126
-    unsigned w[4] = {0, 0, 0, 0};
+    const int r = lane & 31;
+    const size_t rg = rb * 32 + r;
+    const unsigned e = rg < rows ? exps[rg] : 0u;
+    // e == 0: zero/subnormal row -> max_exp 0, zero slices (reference: 0*2 = 0, src/split.cu:191)
+    // e >= 0x7FE: Inf/NaN in the row, or 2^(e+1) not representable -> poisoned row (max_exp = NaN)
+    const bool live = e != 0u && e < 0x7FEu;
+    if (kb == 0 && lane < 32 && rg < rows) {
+      const unsigned long long bits =
+          live ? ((unsigned long long)(e + 1) << 52) : (e == 0u ? 0ull : 0x7FF8000000000000ull);
+      max_exp[rg] = __longlong_as_double((long long)bits);
+    }
+
+    // 128-bit shifted mantissa (hi:lo) = (m53 << 75) >> off, per element (src/split.cu:163-175)
+    unsigned long long hi[16], lo[16];
+    unsigned negmask[4] = {0, 0, 0, 0}; // per packed word: 0xFF in the bytes of negative elements
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-      unsigned long long x;
-      if (p >= 64)
-        x = hi[q] >> (p - 64);
-      else
-        x = (lo[q] >> p) | (hi[q] << (64 - p));
-      w[q >> 2] |= (unsigned)(x & mask) << (8 * (q & 3));
+      const unsigned long long bq = (unsigned long long)__double_as_longlong(v[q]);
+      const unsigned f = (unsigned)(bq >> 52) & 0x7FFu;
+      const unsigned long long m53 = (bq & MANT_MASK) | (f ? (1ull << 52) : 0ull);
+      const unsigned ef = f ? f : 1u; // subnormal: exponent of field 1 (fix of SURVEY §8a quirk 7)
+      const unsigned off = e + 1u - ef; // >= 1 for live rows
+      const unsigned long long V = live ? (m53 << 11) : 0ull;
+      unsigned long long h, l;
+      if (off < 64u) {
+        h = V >> off;
+        l = V << (64u - off); // off >= 1
+      } else if (off < 128u) {
+        h = 0;
+        l = V >> (off - 64u);
+      } else {
+        h = 0;
+        l = 0;
+      }
+      hi[q] = h;
+      lo[q] = l;
+      if (bq >> 63) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
     }
-    uint4 o;
-    unsigned *op = &o.x;
+
+    const unsigned long long mask = (1ull << L) - 1ull;
+    int8_t *out = planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16;
+    for (int s = 0; s < S; s++) {
+      const int p = 128 - (s + 1) * L; // low bit of slice s inside (hi:lo); p >= 2 since S*L <= 126
+      unsigned w[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      // per-byte two's complement of the bytes selected by negmask (values <= 127, SWAR, no carries)
-      const unsigned m = negmask[i], t = w[i] ^ m;
-      op[i] = ((t & 0x7F7F7F7Fu) + (m & 0x01010101u)) ^ (t & 0x80808080u);
+      for (int q = 0; q < 16; q++) {
+        unsigned long long x;
+        if (p >= 64)
+          x = hi[q] >> (p - 64);
+        else
+          x = (lo[q] >> p) | (hi[q] << (64 - p));
+        w[q >> 2] |= (unsigned)(x & mask) << (8 * (q & 3));
+      }
+      uint4 o;
+      unsigned *op = &o.x;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        // per-byte two's complement of the bytes selected by negmask (values <= 127, SWAR, no carries)
+        const unsigned m = negmask[i], tt = w[i] ^ m;
+        op[i] = ((tt & 0x7F7F7F7Fu) + (m & 0x01010101u)) ^ (tt & 0x80808080u);
+      }
+      *(uint4 *)(out + (size_t)s * FRAG_BYTES) = o;
     }
-    *(uint4 *)(out + (size_t)s * FRAG_BYTES) = o;
   }
 }
 
@@ -237,13 +288,17 @@ hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, 
                       double *max_exp, hipStream_t stream) {
   const size_t RB = row_blocks_padded(v.rows), KB = k_blocks(v.K);
   if (RB * KB == 0) return hipSuccess;
-  const unsigned grid = (unsigned)((RB * KB + 3) / 4);
-  if (v.stride_k < v.stride_r)
+  const bool kcontig = v.stride_k < v.stride_r;
+  // strip length: up to 4 blocks per wave as long as >= 2048 workgroups remain to fill the chip
+  const int strip = !kcontig ? 1 : (RB * KB >= 4 * 8192 ? 4 : (RB * KB >= 2 * 8192 ? 2 : 1));
+  const size_t strips = ((kcontig ? KB : RB) + strip - 1) / strip * (kcontig ? RB : KB);
+  const unsigned grid = (unsigned)((strips + 3) / 4);
+  if (kcontig)
     hipLaunchKernelGGL(cut_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB);
+                       exps, S, L, planes, max_exp, RB, KB, strip);
   else
     hipLaunchKernelGGL(cut_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB);
+                       exps, S, L, planes, max_exp, RB, KB, strip);
   return hipGetLastError();
 }
 
