@@ -14,7 +14,8 @@
 // Documented deviations from the reference (SURVEY.md §8a "quirks"):
 //   * `n` is compared with OZIMMU_INTERCEPT_THRESHOLD_N (the reference compares it with _K, src/cublas.cu:145);
 //   * the global handle is created lazily on first use and never dereferenced when absent (:144);
-//   * it is released when the LAST vendor handle created through this shim is destroyed, not on any destroy (:117-126);
+//   * one handle PER DEVICE (workspace on the device that runs the GEMM); all are released when the LAST vendor
+//     handle created through this shim is destroyed, not on any destroy (:117-126);
 //   * an internal failure falls back to the vendor routine instead of reporting SUCCESS (:215-219);
 //   * device pointer mode, out-of-place gemm_ex (C != D) and complex types are passed through untouched;
 //   * a thread-local guard keeps the shim from re-intercepting calls made underneath itself
@@ -27,6 +28,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 
@@ -37,7 +39,9 @@ using namespace ozhip;
 namespace {
 
 std::mutex g_mtx;
-ozimmu_hip_handle_t g_handle = nullptr; // src/cublas.cu:58
+// src/cublas.cu:58 keeps ONE global handle; its workspace lives on whatever device was current at creation, so a
+// process that drives several GPUs would hand device-0 memory to device-1 kernels.  One handle per device here.
+std::map<int, ozimmu_hip_handle_t> g_handles;
 std::atomic<int> g_live_vendor_handles{0};
 thread_local int t_depth = 0;
 
@@ -56,11 +60,14 @@ ozimmu_compute_mode_t get_compute_mode() { return ozimmu_hip_compute_mode_from_s
 // src/cublas.cu:60-86
 ozimmu_hip_handle_t get_global_handle() {
   std::lock_guard<std::mutex> lock(g_mtx);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0; // no device: ozimmu_hip_create below fails and is reported
+  ozimmu_hip_handle_t &g_handle = g_handles[dev];
   if (!g_handle) {
     const ozimmu_malloc_mode_t mm = env_enabled("OZIMMU_MALLOC_ASYNC", false) ? OZIMMU_MALLOC_ASYNC : OZIMMU_MALLOC_SYNC;
     log_info("Initializing ozIMMU handle...");
     if (ozimmu_hip_create(&g_handle, mm) != 0) {
-      g_handle = nullptr;
+      g_handles.erase(dev);
       return nullptr;
     }
     log_info("Successfully initialized");
@@ -203,12 +210,18 @@ rocblas_status rocblas_destroy_handle(rocblas_handle handle) {
   if (!fn) return rocblas_status_internal_error;
   if (t_depth == 0 && g_live_vendor_handles.fetch_sub(1) == 1) {
     std::lock_guard<std::mutex> lock(g_mtx);
-    if (g_handle) {
+    if (!g_handles.empty()) {
       log_info("Destroying ozIMMU handle...");
-      hipDeviceSynchronize(); // the workspace may still be in use by enqueued work
-      DepthGuard guard;       // ozimmu_hip_destroy releases its private vendor handle through this shim
-      ozimmu_hip_destroy(g_handle);
-      g_handle = nullptr;
+      int cur = 0;
+      hipGetDevice(&cur);
+      DepthGuard guard; // ozimmu_hip_destroy releases its private vendor handle through this shim
+      for (auto &kv : g_handles) {
+        hipSetDevice(kv.first);
+        hipDeviceSynchronize(); // the workspace may still be in use by enqueued work
+        ozimmu_hip_destroy(kv.second);
+      }
+      g_handles.clear();
+      hipSetDevice(cur);
     }
   }
   return fn(handle);
