@@ -8,6 +8,8 @@ rounding of the regrouped sum -- tolerance stated in each test.
 import numpy as np
 import pytest
 
+import ozimmu_amd
+
 from oracle import oracle as O
 from tests.util import ColMajor, exp_rand, operand, uniform01, uniform_pm1, wide_exponent
 
@@ -339,3 +341,30 @@ def test_sgemm_mode_matches_an_fp32_product(oz, op_a, op_b, cplx):
         assert np.max(np.abs(got - want) / scale) < 64 * 2.0 ** -24
         np.testing.assert_array_equal(got, got.astype(f32).astype(dt))     # values came out of an FP32 GEMM
         assert np.isnan(c.buf[:, m:]).all()
+
+
+def test_malloc_async_mode_and_side_stream():
+    """OZIMMU_MALLOC_ASYNC / malloc_async (src/handle.cu:63-93): the workspace is (re)allocated in stream order on the
+    caller's stream -- here a non-default stream -- and growing it between calls must not disturb results"""
+    import torch
+    h = ozimmu_amd.create(ozimmu_amd.malloc_async)
+    st = torch.cuda.Stream()
+    try:
+        ozimmu_amd.set_cuda_stream(h, st)
+        rng = np.random.default_rng(21)
+        for (m, n, k, S) in [(64, 64, 64, 6), (300, 200, 500, 9), (70, 33, 129, 13), (512, 384, 1100, 9)]:
+            a = operand("N", m, k, rng, fill=wide_exponent(4), pad=1)
+            b = operand("T", k, n, rng, fill=uniform_pm1, pad=2)
+            c = ColMajor(m, n)
+            c_ref = ColMajor(m, n)
+            with torch.cuda.stream(st):
+                a.dev, b.dev, c.dev  # uploads ordered on the side stream
+            st.synchronize()
+            assert ozimmu_amd.gemm(h, "N", "T", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld,
+                                   f"fp64_int8_{S}") == 0
+            st.synchronize()
+            assert O.gemm("N", "T", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+            np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+    finally:
+        st.synchronize()
+        ozimmu_amd.destroy(h)
