@@ -187,13 +187,13 @@ def main():
                 out["roofline"]["l2_hit_rate"] = round(t.get("l2_hit_rate", 0), 3)
 
         if not args.no_extra:
-            from oracle import oracle as O
+            from tools.residual import sampled_relative_residual  # numpy long double; independent of oracle/
             extra = {}
             # residual vs long-double truth on sampled entries (mateval's relative_residual definition)
             a_h = A.cpu().numpy().T  # column-major views (rows, cols), strides (8, 8*ld)
             b_h = B.cpu().numpy().T
             c_h = Cm.cpu().numpy().T
-            extra["relative_residual"] = O.relative_residual_sampled(opa, opb, M, N, K, a_h, b_h, c_h, ns=2048)
+            extra["relative_residual"] = sampled_relative_residual(opa, opb, M, N, K, a_h, b_h, c_h, ns=2048)
             # native FP64 DGEMM (rocBLAS) on the same inputs
             C2 = torch.zeros_like(Cm)
             for _ in range(2):
@@ -205,7 +205,7 @@ def main():
                 oz.native_dgemm(h, opa, opb, M, N, K, 1.0, A, lda, B, ldb, 0.0, C2, ldc)
             torch.cuda.synchronize()
             extra["rocblas_dgemm_tflops"] = round(flops_per_step * reps / (time.perf_counter() - t1) / 1e12, 3)
-            extra["rocblas_dgemm_relative_residual"] = O.relative_residual_sampled(
+            extra["rocblas_dgemm_relative_residual"] = sampled_relative_residual(
                 opa, opb, M, N, K, a_h, b_h, C2.cpu().numpy().T, ns=2048)
             extra["speedup_vs_rocblas_dgemm"] = round(value / world / extra["rocblas_dgemm_tflops"], 3)
             out["extra"] = extra

@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools.residual import sampled_relative_residual  # noqa: E402  (numpy long double; independent of oracle/)
 
 
 def gen(kind, shape, gen_):
@@ -73,10 +74,7 @@ def eval_one(oz, O, h, kind, op_a, op_b, m, n, k, mode, reps, threshold=0.0, gpu
     rng = np.random.default_rng(1)
     rows = rng.integers(0, m, 2048)
     cols = rng.integers(0, n, 2048)
-    if cplx:
-        res = O.relative_residual_sampled_z(op_a, op_b, m, n, k, a_h, b_h, c_h, ns=2048, seed=1)
-    else:
-        res = O.relative_residual_sampled(op_a, op_b, m, n, k, a_h, b_h, c_h, ns=2048, seed=1)
+    res = sampled_relative_residual(op_a, op_b, m, n, k, a_h, b_h, c_h, ns=2048, seed=1)
     # max relative error on the same kind of sample (long double truth)
     ld = np.clongdouble if cplx else np.longdouble
     aa = (a_h[rows, :] if op_a == "N" else a_h[:, rows].T).astype(ld)
@@ -108,7 +106,7 @@ def main():
     argv = ns.args
     import torch
     import ozimmu_amd as oz
-    from oracle import oracle as O
+    O = None  # the harness does not use the test oracle
     name = torch.cuda.get_device_name(0).replace(" ", "_")
     h = oz.create()
     oz.set_cuda_stream(h, torch.cuda.current_stream())
