@@ -1,0 +1,61 @@
+"""CPU test (hipcc cross-compiles gfx950 without a GPU): properties of the generated ISA that the kernels rely on but
+that the compiler does not know about.
+
+* the lead throttle of slice_gemm_kernel issues `s_load_dword ... glc` from inline asm and consumes the SGPR only after
+  the loop's own `s_waitcnt lgkmcnt(0)`: no instruction may touch that SGPR in between (a compiler-inserted copy would
+  capture a stale value);
+* no slice GEMM or split kernel uses scratch (a spill inside the k loop would be a silent 2x slowdown)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ozimmu_amd", "csrc")
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa")
+    out = {}
+    for src in ("slice_gemm.hip", "split.hip"):
+        o = d / (src + ".s")
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC,
+                               "-D__HIP_PLATFORM_AMD__", "-x", "hip", "--cuda-device-only", "-S",
+                               os.path.join(CSRC, src), "-o", str(o)])
+        out[src] = o.read_text()
+    return out
+
+
+def test_throttle_scalar_load_is_not_touched_before_its_wait(asm):
+    lines = asm["slice_gemm.hip"].split("\n")
+    loads = 0
+    for i, l in enumerate(lines):
+        m = re.search(r"s_load_dword (s\d+), s\[\d+:\d+\], 0x0 glc", l)
+        if not m:
+            continue
+        loads += 1
+        reg = m.group(1)
+        for j in range(i + 1, min(i + 800, len(lines))):
+            lj = lines[j]
+            if "s_waitcnt" in lj and "lgkmcnt(0)" in lj:
+                break
+            assert not (re.search(r"\b" + reg + r"\b", lj) and not lj.strip().startswith(";")), \
+                f"{reg} used before the wait: {lj.strip()}"
+        else:
+            pytest.fail("no s_waitcnt lgkmcnt(0) after the throttle load")
+    assert loads >= 8          # every prefetch-2 instantiation carries the probe
+
+
+def test_kernels_do_not_spill(asm):
+    for src, text in asm.items():
+        for m in re.finditer(r"\.private_segment_fixed_size: (\d+)", text):
+            assert int(m.group(1)) == 0, f"{src}: a kernel uses {m.group(1)} bytes of scratch per lane"
+        names = re.findall(r"\.name:\s+(_ZN5ozhip\w+)", text)
+        assert names, src
