@@ -281,6 +281,23 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     }
   }
 
+  // lead throttle (see the prefetch-2 loop): called by wave 0 with the sampled phase word once it has landed
+  auto throttle = [&](uint32_t hint) {
+    asm volatile("" : "+s"(hint));
+    const uint32_t lead = koff >= hint ? koff - hint : koff + nk - hint; // k-steps ahead of the last publisher
+    if (lead > OZ_THR_LEAD && lead < (nk >> 1)) {
+      // ~one k-step (the MFMAs of this instance, 32 cycles each, x two workgroups per SIMD) per k-step of excess lead
+      const uint32_t units = lead - OZ_THR_LEAD < OZ_THR_MAXU ? lead - OZ_THR_LEAD : OZ_THR_MAXU;
+      constexpr uint32_t PER_UNIT = []() { // MFMAs per k-step of this instance, x 64 cycles
+        uint32_t c = 0;
+        for (int i = 0; i < SL; i++)
+          for (int j = 0; j < SL; j++) c += (i + j >= D0 && i + j < D0 + ND && i + j <= S - 1) ? 1u : 0u;
+        return c;
+      }();
+      for (uint32_t u = 0; u < units * PER_UNIT; u++) __builtin_amdgcn_s_sleep(1);
+    }
+  };
+
   int cur = 0;
   if constexpr ((VAR & VAR_STATIC_PRIO) != 0) {
     // the two workgroups of a CU share each SIMD's matrix pipe; give them different static priorities so that
@@ -334,21 +351,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
       for (int i = 0; i < SL; i++) af[i] = *(const v4i *)(la0 + cur * STAGE_BYTES + i * FRAG_BYTES);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (tr) trp[3] = clock64();
-      if (probe) {
-        asm volatile("" : "+s"(hint)); // the scalar load has landed (lgkmcnt(0) above)
-        const uint32_t lead = koff >= hint ? koff - hint : koff + nk - hint; // k-steps ahead of the last publisher
-        if (lead > OZ_THR_LEAD && lead < (nk >> 1)) {
-          // ~one k-step (P MFMAs of 32 cycles x two workgroups per SIMD) per k-step of excess lead, at most 8
-          const uint32_t units = lead - OZ_THR_LEAD < OZ_THR_MAXU ? lead - OZ_THR_LEAD : OZ_THR_MAXU;
-          constexpr uint32_t PER_UNIT = []() { // MFMAs per k-step of this instance, x 64 cycles
-            uint32_t c = 0;
-            for (int i = 0; i < SL; i++)
-              for (int j = 0; j < SL; j++) c += (i + j >= D0 && i + j < D0 + ND && i + j <= S - 1) ? 1u : 0u;
-            return c;
-          }();
-          for (uint32_t u = 0; u < units * PER_UNIT; u++) __builtin_amdgcn_s_sleep(1);
-        }
-      }
+      if (probe) throttle(hint); // the scalar load has landed (lgkmcnt(0) above)
       __builtin_amdgcn_s_barrier(); // every wave holds its fragments: buffer `cur` is free
       asm volatile("" ::: "memory");
       if (tr) trp[4] = clock64();
@@ -445,6 +448,9 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   } else {
   if (nk) stage(0, p.kb0 + koff);
   for (uint32_t it = 0; it < nk; it++) {
+    uint32_t hint = 0; // lead throttle, as in the prefetch-2 loop: sample now, act at the end of the k-step
+    const bool probe = ABL == 0 && p.throttle && phase && wave == 0 && (it & OZ_THR_MASK) == 1u;
+    if (probe) asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(hint) : "s"(phase) : "memory");
     if constexpr (ABL == 0 || ABL == VAR_SYNC_NO_GLOBAL) {
       __syncthreads(); // own glds landed (vmcnt(0) precedes the barrier) + everyone done with buf cur^1
       if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
@@ -477,6 +483,10 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
             acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af, acc[d - D0], 0, 0, 0);
         }
       }
+    }
+    if (probe) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      throttle(hint);
     }
     cur ^= 1;
   }

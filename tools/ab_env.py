@@ -1,0 +1,22 @@
+"""tools/ab_env.py ENVVAR n mode [mode...] — A/B of a boolean environment switch (read per call) on n^3 GEMMs."""
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+var, n, modes = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+reps = 2 if n > 8192 else 5
+for mode in modes:
+    best = {}
+    for rnd in range(2):
+        for val in ("0", "1"):
+            os.environ[var] = val
+            oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, mode)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps): oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, mode)
+            torch.cuda.synchronize(); best[val] = min(best.get(val, 1e9), (time.perf_counter() - t0) / reps)
+    tf = lambda t: 2.0 * n ** 3 / t / 1e12
+    print(f"n={n} {mode}: {var}=0 {tf(best['0']):6.1f} TF   {var}=1 {tf(best['1']):6.1f} TF   ({(best['1']/best['0']-1)*100:+.1f} % time with =1)", flush=True)
+oz.destroy(h)
