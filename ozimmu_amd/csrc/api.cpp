@@ -148,6 +148,21 @@ static bool run_split(ozimmu_hip_handle_t h, const OperandView &v, uint32_t *exp
          hip_ok(launch_cut(v, exps, S, L, planes, max_exp, h->stream), "cut");
 }
 
+// Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
+struct WorkspaceUse {
+  ozimmu_hip_handle_t h;
+  explicit WorkspaceUse(ozimmu_hip_handle_t handle) : h(handle) {
+    if (h->tail_valid && h->tail_stream != h->stream && !getenv("OZIMMU_HIP_TEST_NO_STREAM_ORDER"))
+      hipStreamWaitEvent(h->stream, h->tail_ev, 0);
+  }
+  ~WorkspaceUse() {
+    if (h->tail_ev && hipEventRecord(h->tail_ev, h->stream) == hipSuccess) {
+      h->tail_stream = h->stream;
+      h->tail_valid = true;
+    }
+  }
+};
+
 static bool ensure_workspace(ozimmu_hip_handle_t h, size_t bytes) {
   ozimmu_hip_reallocate_working_memory(h, bytes);
   return h->working_memory_ptr != nullptr && h->current_working_memory_size >= bytes;
@@ -162,6 +177,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   const bool acc_needed = needs_acc(k, S);
   if (dump && k > kc) return 2; // whole-K INT32 sums would not be exact
   Workspace sz = carve(nullptr, m, n, k, S, acc_needed);
+  WorkspaceUse use(h);
   if (!ensure_workspace(h, sz.total)) return 3;
   Workspace w = carve(h->working_memory_ptr, m, n, k, S, acc_needed);
 
@@ -263,6 +279,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   const size_t kc = max_k_per_pass(S, L);
   const bool acc_needed = needs_acc(k, S);
   WorkspaceZ sz = carve_z(nullptr, m, n, k, S, acc_needed);
+  WorkspaceUse use(h);
   if (!ensure_workspace(h, sz.total)) return 3;
   WorkspaceZ w = carve_z(h->working_memory_ptr, m, n, k, S, acc_needed);
 
@@ -374,6 +391,7 @@ int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm) { //
     return 3;
   }
   for (auto &e : h->ev) hipEventCreate(&e);
+  hipEventCreateWithFlags(&h->tail_ev, hipEventDisableTiming);
   auto read_thr = [](const char *name) -> uint32_t { // std::stoul in the reference (throws); here: default
     const std::string s = load_env_if_defined(name, "1024");
     char *end = nullptr;
@@ -402,6 +420,7 @@ int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
     if (h->d_mantissa_loss_counter_ptr) hipFree(h->d_mantissa_loss_counter_ptr);
     for (auto &e : h->ev)
       if (e) hipEventDestroy(e);
+    if (h->tail_ev) hipEventDestroy(h->tail_ev);
     delete h;
   }
   return 0;
@@ -577,6 +596,7 @@ int ozimmu_hip_gemm_f32(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_o
   const size_t w = cplx ? 2 : 1; // FP32 scalars per element
   // workspace: A32 | B32 | C32, each 256-byte aligned (the reference packs them, :97-100)
   const size_t a_bytes = align256(4 * w * m * k), b_bytes = align256(4 * w * k * n), c_bytes = align256(4 * w * m * n);
+  WorkspaceUse use(h);
   if (!ensure_workspace(h, a_bytes + b_bytes + c_bytes)) return 3;
   float *a32 = (float *)h->working_memory_ptr;
   float *b32 = (float *)((char *)h->working_memory_ptr + a_bytes);
@@ -621,6 +641,7 @@ static int mantissa_loss_impl(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, oz
   const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/split.cu:461
   const int parts = cplx ? 2 : 1;
   const size_t ea = align256(4 * m), eb = align256(4 * n), exps_bytes = parts * (ea + eb);
+  WorkspaceUse use(h);
   if (!ensure_workspace(h, exps_bytes)) return 3;
   char *base = (char *)h->working_memory_ptr;
   bool ok = hip_ok(hipMemsetAsync(base, 0, exps_bytes, h->stream), "memset") &&
@@ -736,6 +757,7 @@ int ozimmu_hip_split_int8(ozimmu_hip_handle_t h, int8_t *out_ptr, uint32_t ldo, 
   std::lock_guard<std::mutex> lock(h->mtx);
   const size_t exps_bytes = align256(4 * v.rows);
   const size_t plane_bytes = tiled_plane_bytes(v.rows, v.K, (int)num_split);
+  WorkspaceUse use(h);
   if (!ensure_workspace(h, exps_bytes + plane_bytes + 256)) return 3;
   uint32_t *exps = (uint32_t *)h->working_memory_ptr;
   int8_t *planes = (int8_t *)h->working_memory_ptr + exps_bytes;

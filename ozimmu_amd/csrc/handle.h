@@ -36,6 +36,12 @@ struct ozimmu_hip_handle {
   float stage_last_ms[3] = {0, 0, 0};
   unsigned long long stage_calls = 0;
 
+  // the workspace is shared by every call on this handle: when the caller switches streams the new stream first
+  // waits for the last user of the workspace (the reference would let the two streams race on it)
+  hipEvent_t tail_ev = nullptr;
+  hipStream_t tail_stream = nullptr;
+  bool tail_valid = false;
+
   // private vendor BLAS handle for the `dgemm` mode (src/handle.hpp:8), created lazily
   void *rocblas_handle = nullptr;
 

@@ -156,3 +156,34 @@ def test_sub_block_consistency_across_tile_shapes(oz, S):
     Cr = torch.empty((n, mb), dtype=torch.float64, device="cuda")
     _gemm(m_, h, "T", "N", mb, n, k, A[i0:i0 + mb], B, Cr, mode)
     assert torch.equal(Cr, C[:, i0:i0 + mb])
+
+
+def test_two_streams_share_one_handle_without_racing_on_the_workspace(oz):
+    """The reference has one global handle and one workspace (src/cublas.cu:58, src/handle.cu:63-93): calls arriving
+    on different streams would overwrite each other's slice planes.  Here a stream switch makes the new stream wait
+    for the previous user of the workspace: back-to-back calls on two streams must both be bit-identical to the
+    same calls issued alone."""
+    import torch
+    m_, h = oz
+    n, mode = 2048, "fp64_int8_9"
+    A1, B1 = _dev_rand((n, n), 31), _dev_rand((n, n), 32)
+    A2, B2 = _dev_rand((n, n), 33, -8.0, 8.0), _dev_rand((n, n), 34)
+    ref1 = torch.empty((n, n), dtype=torch.float64, device="cuda")
+    ref2 = torch.empty_like(ref1)
+    _gemm(m_, h, "N", "N", n, n, n, A1, B1, ref1, mode)
+    _gemm(m_, h, "N", "T", n, n, n, A2, B2, ref2, mode)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    c1 = [torch.zeros_like(ref1) for _ in range(3)]
+    c2 = [torch.zeros_like(ref1) for _ in range(3)]
+    torch.cuda.synchronize()
+    try:
+        for i in range(3):
+            m_.set_cuda_stream(h, s1)
+            assert m_.gemm(h, "N", "N", n, n, n, 1.0, A1, n, B1, n, 0.0, c1[i], n, mode) == 0
+            m_.set_cuda_stream(h, s2)
+            assert m_.gemm(h, "N", "T", n, n, n, 1.0, A2, n, B2, n, 0.0, c2[i], n, mode) == 0
+        torch.cuda.synchronize()
+    finally:
+        m_.set_cuda_stream(h, torch.cuda.current_stream())
+    for i in range(3):
+        assert torch.equal(c1[i], ref1) and torch.equal(c2[i], ref2)
