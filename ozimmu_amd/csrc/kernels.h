@@ -31,7 +31,7 @@ struct SliceGemmArgs {
   uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue
-  unsigned long long *trace; // development only (tools/gemm_ablate.hip, VAR_TRACE)
+  unsigned long long *trace; // development only: per-phase stamps of tools/slice_gemm_pp_kernel.h
   uint32_t trace_block0;     // first traced workgroup id
 };
 

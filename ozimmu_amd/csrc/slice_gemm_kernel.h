@@ -1,6 +1,11 @@
 // slice_gemm_kernel.h — device code of the fused INT8 slice GEMM (see slice_gemm.hip for the design notes).
-// Kept in a header so that tools/gemm_ablate.hip can instantiate experimental variants (VAR != 0) of the
-// very same kernel for within-process A/B timing; the library only instantiates VAR = 0.
+//
+// Kept in a header so that tools/gemm_ablate.hip can instantiate MEASUREMENT variants of the very same kernel for
+// within-process A/B timing.  The VAR template argument is a bit set: the library ships
+// VAR_SHIPPED (prefetch distance 2) or VAR_SHIPPED & ~VAR_PF2 (prefetch distance 1, slice_gemm.hip picks); every other
+// bit is a probe that removes work or redirects addresses to time a component -- probes marked "wrong results" must
+// never be launched by the library.  Optimisation variants that were measured and rejected (MUBUF copies, register
+// staging, priorities, interleaved copies, per-phase traces) live in the git history and in DESIGN.md, not here.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,8 +17,8 @@ namespace ozhip {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// cache policy of the LDS-DMA copies (cpol immediate: bit 0 sc0, bit 1 nt, bit 4 sc1); overridable for experiments
-#ifndef OZ_THR_MASK // lead-throttle parameters (VAR_THROTTLE)
+// lead-throttle parameters: probe every (MASK+1)-th k-step, tolerate LEAD k-steps, sleep at most MAXU units
+#ifndef OZ_THR_MASK
 #define OZ_THR_MASK 15u
 #endif
 #ifndef OZ_THR_LEAD
@@ -22,37 +27,30 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #ifndef OZ_THR_MAXU
 #define OZ_THR_MAXU 8u
 #endif
+// cache policy of the LDS-DMA copies (cpol immediate: bit 0 sc0, bit 1 nt, bit 4 sc1); measured: nt -25 %, sc* neutral
 #ifndef OZ_GLDS_AUX
 #define OZ_GLDS_AUX 0
 #endif
 #define OZ_AS1 __attribute__((address_space(1)))
 #define OZ_AS3 __attribute__((address_space(3)))
 
-// VAR bits (experiments only): low 2 bits = ablation: 1 = no HBM->LDS staging and no barriers (LDS holds
-// garbage), 2 = MFMA only (no LDS reads either).
+// ---- VAR bits -----------------------------------------------------------------------------------------------
+// shipped behaviour
+constexpr int VAR_PF2 = 8;       // main loop with prefetch distance 2 (fragments in registers); else distance 1
+constexpr int VAR_PH_EVERY = 32; // publish the phase hint every k-step (else every 8th)
+constexpr int VAR_PH_LEAD2 = 64; // late joiners start 2 k-steps ahead of the published phase
+constexpr int VAR_SADDR = 1024;  // copies: scalar base + one lane-offset VGPR, immediate offsets 0/1024/2048
+constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2 | VAR_SADDR;
+// ablations (low 3 bits, timing only: LDS holds garbage)
 constexpr int VAR_ABL_MASK = 7;
-constexpr int VAR_NO_GLOBAL = 1;
-constexpr int VAR_MFMA_ONLY = 2;
-constexpr int VAR_REG_STAGE = 32768; // stage through registers: global_load_dwordx4 -> VGPR -> ds_write_b128 (no LDS-DMA)
-constexpr int VAR_RAND_REGS = 16384;
-constexpr int VAR_HOT1 = 131072; // timing probe (wrong results): every copy of a wave re-reads ONE 1 KiB block (L1 hits)
-constexpr int VAR_HOT = 65536; // timing probe (wrong results): every copy reads an L2-resident 1 MiB region // with VAR_MFMA_ONLY: full-entropy operands (power / clock probe)
-constexpr int VAR_GLOBAL_NO_SYNC = 3; // staging issued but never waited for / no barrier (races; timing only)
-constexpr int VAR_SYNC_NO_GLOBAL = 4; // barrier every k-step but no staging
-constexpr int VAR_GLOBAL_TO_REG = 5;  // staging loads go to registers (no LDS-DMA write), never used
-constexpr int VAR_PF2 = 8;            // main loop with prefetch distance 2 (fragments in registers)
+constexpr int VAR_NO_GLOBAL = 1;      // no HBM->LDS staging and no barriers
+constexpr int VAR_MFMA_ONLY = 2;      // no LDS reads either: operands are registers
+constexpr int VAR_SYNC_NO_GLOBAL = 4; // barrier every k-step but no staging (prefetch-1 loop)
+// probes
 constexpr int VAR_NO_CU_SWIZZLE = 16; // plain (p%8, p/8) tile order inside a patch
-constexpr int VAR_PH_EVERY = 32;      // publish the phase hint every k-step
-constexpr int VAR_PH_LEAD2 = 64;      // late joiners start 2 k-steps ahead of the published phase
-constexpr int VAR_MUBUF = 2048;       // staging with buffer_load ... lds (SGPR resource) instead of global_load_lds
-constexpr int VAR_SADDR = 1024;       // staging: one address + M0 per 3 fragment blocks, immediate offsets 0/1024/2048
-constexpr int VAR_STATIC_PRIO = 4096; // odd/even workgroup generations get different s_setprio
-constexpr int VAR_KICK_PRIO = 8192;   // pseudo-random s_setprio per MFMA burst (breaks in-phase lock of co-resident workgroups)
-constexpr int VAR_SETPRIO = 128;      // s_setprio(1) around the MFMA burst of the prefetch-2 loop
-constexpr int VAR_TRACE = 512;        // record shader-clock stamps (SliceGemmArgs::trace), development only
-constexpr int VAR_INTERLEAVE = 256;   // prefetch-2 loop: issue the refill copies one per A-slice between the MFMAs
-// what the library ships (tools/gemm_ablate.hip A/B, N=8192 S=9: 18.9 ms vs 20.0 ms for VAR=0)
-constexpr int VAR_SHIPPED = VAR_PF2 | VAR_PH_EVERY | VAR_PH_LEAD2 | VAR_SADDR; // MUBUF staging: +5 % at 4096^3, -10 % at 16384^3
+constexpr int VAR_RAND_REGS = 16384;  // with VAR_MFMA_ONLY: full-entropy operands (power / clock probe)
+constexpr int VAR_HOT = 65536;        // wrong results: every copy reads an L2-resident 1 MiB window
+constexpr int VAR_HOT1 = 131072;      // wrong results: every copy of a wave re-reads ONE 1 KiB block (L1 hits)
 
 // 2^e as a double, e in the normal range
 __device__ __forceinline__ double pow2d(int e) {
@@ -112,7 +110,7 @@ __device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, cons
 }
 
 // WM = A row-blocks (of 32 rows) per workgroup: 2 -> 4 waves, 64x64 tile, two workgroups per CU;
-//                                            4 -> 8 waves, 128x64 tile, one workgroup per CU (-25 % staged bytes per MFMA)
+//                                            4 -> 8 waves, 128x64 tile (-25 % staged bytes per MFMA)
 template <int S, int D0, int ND, int VAR = 0, int WM = 2>
 __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemmArgs p) {
   // slices 0..SL-1 of both operands are needed for diagonals d=i+j in [D0, D0+ND)
@@ -162,53 +160,29 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     }
   }
 
-  // ---- staging: wave w copies row-block w of {A0, A1, B0, B1}, SL fragment blocks per k-step -------
+  // ---- staging: wave w copies row-block w of {A0.., B0, B1}, SL fragment blocks per k-step ---------
   constexpr uint32_t RB_MASK = (VAR & VAR_HOT) ? 7u : ~0u, KB_MASK = (VAR & VAR_HOT) ? 15u : ~0u;
-  const int8_t *src = (wave < WM)
-                          ? p.a_planes + (size_t)((WM * tm + wave) & RB_MASK) * p.KB * (size_t)(S * FRAG_BYTES)
-                          : p.b_planes + (size_t)((2 * tn + (wave - WM)) & RB_MASK) * p.KB * (size_t)(S * FRAG_BYTES);
-  const bool stager = wave < WM + 2; // WM = 4: waves 6,7 stage nothing
-  const int8_t *src_u = src;                 // wave-uniform part (SGPRs)
-  // MUBUF staging: one buffer resource per wave over ITS row-block (K/32 * S KiB, always < 4 GiB), 32-bit offsets
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)src_u, 0, (int)(p.KB * (uint32_t)(S * FRAG_BYTES)), 0x00020000);
+  const int8_t *src_u = // wave-uniform (SGPRs)
+      (wave < WM) ? p.a_planes + (size_t)((WM * tm + wave) & RB_MASK) * p.KB * (size_t)(S * FRAG_BYTES)
+                  : p.b_planes + (size_t)((2 * tn + (wave - WM)) & RB_MASK) * p.KB * (size_t)(S * FRAG_BYTES);
+  const bool stager = wave < WM + 2;              // WM = 4: waves 6,7 stage nothing
   const uint32_t lane_off = (uint32_t)lane * 16u; // per-lane part (one VGPR)
-  src += lane * 16;
-  v4i regstage[SL]; // VAR_GLOBAL_TO_REG only
   auto stage = [&](int buf, uint32_t kb) {
     kb &= KB_MASK;
-    if constexpr (ABL == VAR_GLOBAL_TO_REG) { // same HBM/L2 traffic, but no LDS write: isolates the LDS-DMA cost
-      const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
-#pragma unroll
-      for (int s = 0; s < SL; s++) asm volatile("" ::"v"(regstage[s])); // previous data must have landed
-#pragma unroll
-      for (int s = 0; s < SL; s++) regstage[s] = *(const v4i *)(g + s * FRAG_BYTES);
-      return;
-    }
-    if constexpr (ABL != 0 && ABL != VAR_GLOBAL_NO_SYNC) return;
+    if constexpr (ABL != 0) return;
     if (!stager) return;
     char *l = smem + buf * STAGE_BYTES + wave * (SL * FRAG_BYTES);
     if constexpr ((VAR & VAR_HOT1) != 0) {
 #pragma unroll
       for (int s = 0; s < SL; s++)
-        __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)src, (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(src_u + lane_off), (OZ_AS3 void *)(l + s * FRAG_BYTES),
+                                         16, 0, 0);
       return;
     }
-    if constexpr ((VAR & VAR_MUBUF) != 0) {
-      // MUBUF form (buffer_load ... lds): SGPR resource + ONE lane-offset VGPR + SGPR byte offset.  Under MFMA load a
-      // wave issues these in ~60 cycles each, against ~140 for global_load_lds with a 64-bit VGPR address pair
-      // (tools/gemm_ablate.hip trace: stage issue 540 vs 1240 cycles per k-step)
-      const uint32_t so = kb * (uint32_t)(S * FRAG_BYTES);
-#pragma unroll
-      for (int s = 0; s < SL; s++)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, lane_off,
-                                             so + s * FRAG_BYTES, 0, 0);
-      return;
-    }
+    const int8_t *gu = src_u + (size_t)kb * (S * FRAG_BYTES);
     if constexpr ((VAR & VAR_SADDR) != 0) {
       // scalar base (SGPR pair) + one 32-bit lane offset VGPR, and the instruction's immediate offset walks
-      // 4 consecutive fragment blocks (it advances the LDS address too): 3 address/M0 set-ups per stage, not 9
-      const int8_t *gu = src_u + (size_t)kb * (S * FRAG_BYTES);
+      // 3 consecutive fragment blocks (it advances the LDS address too): 3 address/M0 set-ups per stage, not 9
 #pragma unroll
       for (int s = 0; s < SL; s++) {
         constexpr int G = 3; // blocks per immediate-offset group: offsets 0, 1024, 2048 (< 4096)
@@ -225,10 +199,9 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
       }
       return;
     }
-    const int8_t *g = src + (size_t)kb * (S * FRAG_BYTES);
 #pragma unroll
     for (int s = 0; s < SL; s++)
-      __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(g + s * FRAG_BYTES),
+      __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + s * FRAG_BYTES + lane_off),
                                        (OZ_AS3 void *)(l + s * FRAG_BYTES), 16, 0, OZ_GLDS_AUX);
   };
 
@@ -245,9 +218,8 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   // workgroup that starts late therefore begins at the k-block its neighbours are currently at (a racy,
   // advisory word per XCD) and wraps around.  Performance only: any value gives the same result.
   const uint32_t nk = p.kb1 - p.kb0;
-  // one 256-byte line per XCD; published with a PLAIN store (stays in that XCD's L2, no fabric write)
-  // every 8th k-step: a same-address write-through from 512 workgroups per k-step saturates the memory
-  // side (measured 8x slowdown).
+  // one 256-byte line per XCD, published with a PLAIN store (stays in that XCD's L2, no fabric write): a
+  // same-address write-through from 512 workgroups per k-step saturates the memory side (measured 8x slowdown).
   uint32_t *phase = p.phase ? p.phase + 64u * (blockIdx.x & 7u) : nullptr;
   uint32_t koff = 0;
   if (phase && nk > 1) {
@@ -281,8 +253,18 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     }
   }
 
-  // lead throttle (see the prefetch-2 loop): called by wave 0 with the sampled phase word once it has landed
-  auto throttle = [&](uint32_t hint) {
+  // ---- lead throttle ---------------------------------------------------------------------------------------
+  // Workgroups of an XCD share A/B panels through its L2 only while they are within the L2's retention window of
+  // each other (~14 k-steps of patch traffic); they start aligned (phase hint) but drift.  Every 16th k-step wave 0
+  // samples the phase word with a scalar load (issued early, consumed after a later `s_waitcnt lgkmcnt(0)`) and, if
+  // this workgroup is more than 2 k-steps ahead of the last publisher, sleeps before it releases the k-step's
+  // barrier: leaders wait for the pack instead of missing in L2 (L2 hit 74 -> 86 %, fabric fetch 41 -> 21 GB at
+  // 8192^3 S=9).  Pays off for long K (+1..4 % at 8192^3 / 16384^3); the host enables it for K >= 6144 only.
+  auto throttle_probe = [&](uint32_t it) { return p.throttle && phase && wave == 0 && (it & OZ_THR_MASK) == 1u; };
+  auto throttle_sample = [&](uint32_t &hint) {
+    asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(hint) : "s"(phase) : "memory");
+  };
+  auto throttle = [&](uint32_t hint) { // call only after lgkmcnt(0) (tests/test_isa_invariants.py checks the ISA)
     asm volatile("" : "+s"(hint));
     const uint32_t lead = koff >= hint ? koff - hint : koff + nk - hint; // k-steps ahead of the last publisher
     if (lead > OZ_THR_LEAD && lead < (nk >> 1)) {
@@ -299,11 +281,6 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   };
 
   int cur = 0;
-  if constexpr ((VAR & VAR_STATIC_PRIO) != 0) {
-    // the two workgroups of a CU share each SIMD's matrix pipe; give them different static priorities so that
-    // their MFMA bursts serialise (one computes while the other stages) instead of interleaving in phase
-    if (__builtin_amdgcn_readfirstlane((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_setprio(2);
-  }
   if constexpr ((VAR & VAR_PF2) != 0) {
     // ---- prefetch distance 2 on two LDS buffers ------------------------------------------------------
     // The HBM/L2 -> LDS stream is latency bound (Little: bytes in flight / latency): with one stage in
@@ -322,175 +299,89 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
     const char *la0 = smem + wm * (SL * FRAG_BYTES) + lane * 16;
     const char *lb0 = smem + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
     for (uint32_t it = 0; it < nk; it++) {
-      // development trace (VAR_TRACE): shader-clock stamps of one wave per workgroup for 16 k-steps
-      const uint32_t trb = blockIdx.x - p.trace_block0;
-      const bool tr = (VAR & VAR_TRACE) != 0 && p.trace && it >= 64 && it < 80 && lane == 0 && trb < 64;
-      unsigned long long *trp = tr ? p.trace + ((size_t)(trb * 8 + wave) * 16 + (it - 64)) * 8 : nullptr;
-      if (tr) trp[0] = clock64();
       if (it + 1 < nk)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (tr) trp[1] = clock64();
       uint32_t hint = 0;
-      // Lead throttle.  Workgroups of an XCD share A/B panels through its L2 only while they are within the L2's
-      // retention window of each other (~14 k-steps of patch traffic); they start aligned (phase hint) but drift.
-      // Every 16th k-step wave 0 samples the phase word (scalar load, consumed after the lgkmcnt(0) below) and, if
-      // this workgroup is more than 2 k-steps ahead of the last publisher, sleeps before releasing the barrier:
-      // leaders wait for the pack instead of missing in L2.  Pays off for long K (drift grows with the number of
-      // k-steps): +1..4 % at 8192^3 / 16384^3, neutral below; the host enables it for K >= 6144 only.
-      const bool probe = p.throttle && phase && wave == 0 && (it & OZ_THR_MASK) == 1u;
-      if (probe) asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(hint) : "s"(phase) : "memory");
+      const bool probe = throttle_probe(it);
+      if (probe) throttle_sample(hint);
       __builtin_amdgcn_s_barrier(); // stage `it` is in LDS for every wave
       asm volatile("" ::: "memory");
-      if (tr) trp[2] = clock64();
       v4i bf[SL], af[SL];
 #pragma unroll
       for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb0 + cur * STAGE_BYTES + j * FRAG_BYTES);
 #pragma unroll
       for (int i = 0; i < SL; i++) af[i] = *(const v4i *)(la0 + cur * STAGE_BYTES + i * FRAG_BYTES);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (tr) trp[3] = clock64();
-      if (probe) throttle(hint); // the scalar load has landed (lgkmcnt(0) above)
+      if (probe) throttle(hint);
       __builtin_amdgcn_s_barrier(); // every wave holds its fragments: buffer `cur` is free
       asm volatile("" ::: "memory");
-      if (tr) trp[4] = clock64();
       if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
         __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       koff = koff_next(koff);
-      const bool refill = it + 2 < nk;
-      if constexpr ((VAR & VAR_INTERLEAVE) == 0) {
-        if (refill) stage(cur, p.kb0 + k_issue);
+      if (it + 2 < nk) {
+        stage(cur, p.kb0 + k_issue);
+        k_issue = koff_next(k_issue);
       }
-      if (tr) trp[5] = clock64();
-      if constexpr ((VAR & VAR_SETPRIO) != 0) __builtin_amdgcn_s_setprio(1);
-      if constexpr ((VAR & VAR_KICK_PRIO) != 0) {
-        // pseudo-random priority for this MFMA burst: if the partner workgroup's burst overlaps ours, one of the
-        // two wins the pipe outright about half of the time, which pushes the pair into the anti-phase state
-        // (one computes while the other stages) -- a state that then persists by itself
-        const uint32_t hsh = (blockIdx.x * 2654435761u + it * 40503u) >> 13;
-        if (__builtin_amdgcn_readfirstlane(hsh & 1u)) __builtin_amdgcn_s_setprio(2);
-      }
-#pragma unroll
-      for (int i = 0; i < SL; i++) {
-        if constexpr ((VAR & VAR_INTERLEAVE) != 0) {
-          // one 1 KiB LDS-DMA per A-slice row of MFMAs: the copies trickle into the texture path while the
-          // matrix pipe works, instead of 4..8 waves queueing 9 copies each behind the barrier
-          if (refill && stager && ABL == 0) {
-            const int8_t *g = src + (size_t)(p.kb0 + k_issue) * (S * FRAG_BYTES) + i * FRAG_BYTES;
-            char *l = smem + cur * STAGE_BYTES + wave * (SL * FRAG_BYTES) + i * FRAG_BYTES;
-            __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)g, (OZ_AS3 void *)l, 16, 0, OZ_GLDS_AUX);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < SL; j++) {
-          const int d = i + j;
-          if (d >= D0 && d < D0 + ND && d <= S - 1)
-            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[d - D0], 0, 0, 0);
-        }
-        if constexpr ((VAR & VAR_INTERLEAVE) != 0) __builtin_amdgcn_sched_barrier(0);
-      }
-      if (refill) k_issue = koff_next(k_issue);
-      if (tr) trp[6] = clock64();
-      if constexpr ((VAR & (VAR_SETPRIO | VAR_KICK_PRIO)) != 0) __builtin_amdgcn_s_setprio(0);
-      cur ^= 1;
-    }
-  } else if constexpr ((VAR & VAR_REG_STAGE) != 0) {
-    // ---- register-staged double buffer ---------------------------------------------------------------
-    // The loads of stage it+1 are plain global_load_dwordx4 into VGPRs, issued BEFORE the MFMAs of stage it (they
-    // cost a few issue cycles each and complete in the background); after the MFMAs the wave writes them to the
-    // other LDS buffer with ds_write_b128 and joins the single barrier of the k-step.
-    static_assert(WM == 2, "every wave stages one row-block");
-    const int8_t *gu = src_u + lane_off;
-    char *lw = smem + wave * (SL * FRAG_BYTES) + lane * 16;
-    v4i rs[SL];
-    if (nk) {
-      const int8_t *g = gu + (size_t)(p.kb0 + koff) * (S * FRAG_BYTES);
-#pragma unroll
-      for (int s = 0; s < SL; s++) rs[s] = *(const v4i *)(g + s * FRAG_BYTES);
-#pragma unroll
-      for (int s = 0; s < SL; s++) *(v4i *)(lw + s * FRAG_BYTES) = rs[s];
-    }
-    __syncthreads();
-    for (uint32_t it = 0; it < nk; it++) {
-      if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
-        __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      koff = koff + 1 == nk ? 0 : koff + 1;
-      const bool more = it + 1 < nk;
-      if (more) {
-        const int8_t *g = gu + (size_t)(p.kb0 + koff) * (S * FRAG_BYTES);
-#pragma unroll
-        for (int s = 0; s < SL; s++) rs[s] = *(const v4i *)(g + s * FRAG_BYTES);
-      }
-      const char *la = smem + cur * STAGE_BYTES + wm * (SL * FRAG_BYTES) + lane * 16;
-      const char *lb = smem + cur * STAGE_BYTES + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
-      v4i bf[SL];
-#pragma unroll
-      for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb + j * FRAG_BYTES);
-#pragma unroll
-      for (int i = 0; i < SL; i++) {
-        const v4i af = *(const v4i *)(la + i * FRAG_BYTES);
-#pragma unroll
-        for (int j = 0; j < SL; j++) {
-          const int d = i + j;
-          if (d >= D0 && d < D0 + ND && d <= S - 1)
-            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af, acc[d - D0], 0, 0, 0);
-        }
-      }
-      if (more) {
-#pragma unroll
-        for (int s = 0; s < SL; s++) *(v4i *)(lw + (cur ^ 1) * STAGE_BYTES + s * FRAG_BYTES) = rs[s];
-      }
-      __syncthreads();
-      cur ^= 1;
-    }
-  } else {
-  if (nk) stage(0, p.kb0 + koff);
-  for (uint32_t it = 0; it < nk; it++) {
-    uint32_t hint = 0; // lead throttle, as in the prefetch-2 loop: sample now, act at the end of the k-step
-    const bool probe = ABL == 0 && p.throttle && phase && wave == 0 && (it & OZ_THR_MASK) == 1u;
-    if (probe) asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(hint) : "s"(phase) : "memory");
-    if constexpr (ABL == 0 || ABL == VAR_SYNC_NO_GLOBAL) {
-      __syncthreads(); // own glds landed (vmcnt(0) precedes the barrier) + everyone done with buf cur^1
-      if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
-        __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    koff = koff + 1 == nk ? 0 : koff + 1;
-    if (it + 1 < nk) stage(cur ^ 1, p.kb0 + koff);
-    const char *la = smem + cur * STAGE_BYTES + wm * (SL * FRAG_BYTES) + lane * 16;
-    const char *lb = smem + cur * STAGE_BYTES + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
-    if constexpr (ABL == VAR_MFMA_ONLY) {
 #pragma unroll
       for (int i = 0; i < SL; i++)
 #pragma unroll
         for (int j = 0; j < SL; j++) {
           const int d = i + j;
           if (d >= D0 && d < D0 + ND && d <= S - 1)
-            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf[RAND_REGS ? j : (j & 1)], cf[RAND_REGS ? i : (i & 1)], acc[d - D0], 0, 0, 0);
+            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[d - D0], 0, 0, 0);
         }
-    } else {
-      v4i bf[SL];
+      cur ^= 1;
+    }
+  } else {
+    // ---- prefetch distance 1: one __syncthreads per k-step, A fragments streamed from LDS --------------
+    if (nk) stage(0, p.kb0 + koff);
+    for (uint32_t it = 0; it < nk; it++) {
+      uint32_t hint = 0; // lead throttle: sample now, act at the end of the k-step
+      const bool probe = ABL == 0 && throttle_probe(it);
+      if (probe) throttle_sample(hint);
+      if constexpr (ABL == 0 || ABL == VAR_SYNC_NO_GLOBAL) {
+        __syncthreads(); // own copies landed (vmcnt(0) precedes the barrier) + everyone done with buf cur^1
+        if (phase && (it & PH_MASK) == 0 && threadIdx.x == 0)
+          __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      koff = koff + 1 == nk ? 0 : koff + 1;
+      if (it + 1 < nk) stage(cur ^ 1, p.kb0 + koff);
+      const char *la = smem + cur * STAGE_BYTES + wm * (SL * FRAG_BYTES) + lane * 16;
+      const char *lb = smem + cur * STAGE_BYTES + (WM + wn) * (SL * FRAG_BYTES) + lane * 16;
+      if constexpr (ABL == VAR_MFMA_ONLY) {
 #pragma unroll
-      for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb + j * FRAG_BYTES);
+        for (int i = 0; i < SL; i++)
 #pragma unroll
-      for (int i = 0; i < SL; i++) {
-        const v4i af = *(const v4i *)(la + i * FRAG_BYTES);
+          for (int j = 0; j < SL; j++) {
+            const int d = i + j;
+            if (d >= D0 && d < D0 + ND && d <= S - 1)
+              acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cf[RAND_REGS ? j : (j & 1)],
+                                                                  cf[RAND_REGS ? i : (i & 1)], acc[d - D0], 0, 0, 0);
+          }
+      } else {
+        v4i bf[SL];
 #pragma unroll
-        for (int j = 0; j < SL; j++) {
-          const int d = i + j;
-          if (d >= D0 && d < D0 + ND && d <= S - 1)
-            acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af, acc[d - D0], 0, 0, 0);
+        for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb + j * FRAG_BYTES);
+#pragma unroll
+        for (int i = 0; i < SL; i++) {
+          const v4i af = *(const v4i *)(la + i * FRAG_BYTES);
+#pragma unroll
+          for (int j = 0; j < SL; j++) {
+            const int d = i + j;
+            if (d >= D0 && d < D0 + ND && d <= S - 1)
+              acc[d - D0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af, acc[d - D0], 0, 0, 0);
+          }
         }
       }
+      if (probe) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        throttle(hint);
+      }
+      cur ^= 1;
     }
-    if (probe) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      throttle(hint);
-    }
-    cur ^= 1;
   }
-  } // !VAR_PF2
 
   // ---- epilogue ------------------------------------------------------------------------------------
   recombine_and_store<D0, ND>(p, acc, tm * (32 * WM) + wm * 32 + (lane & 31), tn * 64 + wn * 32 + 4 * (lane >> 5));

@@ -1,7 +1,7 @@
 // tools/gemm_ablate.hip — within-process A/B timing of slice_gemm_kernel variants (kernel development tool,
 // not part of the library).  Build + run on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iozimmu_amd/csrc tools/gemm_ablate.hip -o gpurun_out/gemm_ablate
-//   gpurun_out/gemm_ablate [N=8192] [rounds=5]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iozimmu_amd/csrc -Itools tools/gemm_ablate.hip -o tools/bin/gemm_ablate
+//   tools/bin/gemm_ablate [N=8192] [rounds=5] [plane value mask: 127 = full-entropy slices, 1 = low-toggle data]
 // Random INT8 planes (full-range 7-bit magnitudes with random sign, like real slices of U[-1,1) data),
 // variants interleaved round-robin, median/min per variant (guide §5.4 rules 24/25).
 #include <hip/hip_runtime.h>
@@ -148,8 +148,7 @@ int main(int argc, char **argv) {
       {"ping-pong 64x128", run_pp<S, 0>, false, {}},
       {"ping-pong 64x128 MUBUF", run_pp<S, 2>, false, {}},
       {"shipped + lead throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
-      {"MUBUF copies", run<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>, false, {}},
-      {"MUBUF copies + throttle", run_throttled<S, (VAR_SHIPPED & ~VAR_SADDR) | VAR_MUBUF>, false, {}},
+      {"prefetch-1 loop (as S >= 11)", run_throttled<S, VAR_SHIPPED & ~VAR_PF2>, false, {}},
       {"shipped, L2-hot addresses", run<S, VAR_SHIPPED | VAR_HOT>, false, {}},
       {"shipped, L1-hot addresses", run<S, VAR_SHIPPED | VAR_HOT1>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
