@@ -368,3 +368,32 @@ def test_malloc_async_mode_and_side_stream():
     finally:
         st.synchronize()
         ozimmu_amd.destroy(h)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gemm_fuzz_bit_exact(oz, seed):
+    """seeded fuzz over shapes (ragged, tiny, one tile row/column short of a boundary), all op pairs, S = 3..18,
+    alpha/beta, leading-dimension padding and input distributions: every case bit-exact against the oracle"""
+    m_, h = oz
+    rng = np.random.default_rng(9000 + seed)
+    fills = [uniform_pm1, uniform01, exp_rand(2.0), wide_exponent(8)]
+    for case in range(10):
+        edge = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 257]
+        m = int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, 300))
+        n = int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, 300))
+        k = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 255, 256, 257, 640])) if rng.random() < 0.5 \
+            else int(rng.integers(1, 700))
+        S = int(rng.integers(3, 19))
+        op_a, op_b = rng.choice(OPS), rng.choice(OPS)
+        alpha = float(rng.choice([1.0, -1.0, 0.5, 3.25]))
+        beta = float(rng.choice([0.0, 0.0, 1.0, -0.75]))
+        a = operand(op_a, m, k, rng, fill=fills[int(rng.integers(4))], pad=int(rng.integers(0, 4)))
+        b = operand(op_b, k, n, rng, fill=fills[int(rng.integers(4))], pad=int(rng.integers(0, 4)))
+        c = ColMajor(m, n, ld=m + int(rng.integers(0, 3)), fill=uniform_pm1, rng=rng)
+        c_ref = ColMajor(m, n, ld=c.ld)
+        c_ref.buf[...] = c.buf
+        assert _run_gemm(m_, h, op_a, op_b, m, n, k, alpha, a, b, beta, c, f"fp64_int8_{S}") == 0
+        assert O.gemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+        got = c.download()
+        assert np.array_equal(got.view(np.uint64), c_ref.view.view(np.uint64)), \
+            (seed, case, op_a, op_b, m, n, k, S, alpha, beta)
