@@ -188,6 +188,26 @@ def test_gemm_k_chunking_large_k(oz):
     np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
 
 
+@pytest.mark.parametrize("m,n,k,S", [(40, 24, 140000, 9), (40, 24, 140000, 14), (24, 24, 530000, 9)])
+def test_gemm_narrow_slices_for_very_long_k(oz, m, n, k, S):
+    """k > 2^17 -> 6-bit slices, k > 2^19 -> 5-bit slices (get_bits_per_int8, src/split.cu:520-536); the INT32-safe
+    pass length follows (2^L - 1)^2, and S = 14 combines K-chunking with the two diagonal passes"""
+    m_, h = oz
+    L = O.bits_per_int8(k)
+    assert L == (6 if k < (1 << 19) else 5)
+    rng = np.random.default_rng(k + S)
+    a = operand("T", m, k, rng, fill=wide_exponent(3))
+    b = operand("N", k, n, rng)
+    c = ColMajor(m, n)
+    c_ref = ColMajor(m, n)
+    assert _run_gemm(m_, h, "T", "N", m, n, k, 1.0, a, b, 0.0, c, f"fp64_int8_{S}") == 0
+    kchunk = (2147483647 // (S * ((1 << L) - 1) ** 2)) // 32 * 32
+    O.gemm("T", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL, kchunk=kchunk)
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+    assert O.relative_residual(
+        "T", "N", m, n, k, a.view, b.view, c.view) < (1e-13 if S * L >= 54 else 1e-9)
+
+
 def test_gemm_argument_errors(oz):
     """src/gemm.cu:535-556: bad leading dimension / misaligned pointer -> 1, nothing written"""
     import torch
