@@ -149,6 +149,7 @@ int main(int argc, char **argv) {
       {"ping-pong 64x128 MUBUF", run_pp<S, 2>, false, {}},
       {"shipped + lead throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
       {"prefetch-1 loop (as S >= 11)", run_throttled<S, VAR_SHIPPED & ~VAR_PF2>, false, {}},
+      {"throttle, plain patch order", run_throttled<S, VAR_SHIPPED | VAR_NO_CU_SWIZZLE>, false, {}},
       {"shipped, L2-hot addresses", run<S, VAR_SHIPPED | VAR_HOT>, false, {}},
       {"shipped, L1-hot addresses", run<S, VAR_SHIPPED | VAR_HOT1>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
