@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libozimmu_hip.so")
 SOURCES = ["slice_gemm.hip", "split.hip", "convert.hip", "api.cpp", "interpose.cpp"]
-HEADERS = ["kernels.h", "layout.h", "handle.h", "slice_gemm_kernel.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
+HEADERS = ["kernels.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
 ARCH = "gfx950"
 
 

@@ -61,6 +61,7 @@ static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 // largest K (multiple of 32) whose per-diagonal INT32 sums cannot overflow: at most S products of
 // magnitude <= (2^L-1)^2 per k.  (The reference bounds a single pair: k*2^(2L) <= 2^31, src/split.cu:520-536.)
 static size_t max_k_per_pass(int S, int L) {
+  if (L <= 0 || S <= 0) return 32; // no safe slice width (k == 0 or k > 2^30): callers route such calls elsewhere
   const unsigned long long q = (1ull << L) - 1ull;
   const unsigned long long kc = 2147483647ull / ((unsigned long long)S * q * q);
   return (size_t)std::max<unsigned long long>(32ull, kc / 32ull * 32ull);
@@ -103,8 +104,14 @@ static uint32_t throttle_for(size_t m, size_t n, size_t k) {
   return (k >= 6144 && ((m + 63) / 64) * ((n + 63) / 64) >= 2048) ? 1u : 0u;
 }
 
+// slice width for a K of this length; 0 when none is safe (k == 0, k > 2^30: src/split.cu:520-536 wraps there)
+static int bits_for_k(size_t k) {
+  return k > (size_t)1 << 30 ? 0 : (int)ozimmu_hip_get_bits_per_int8((uint32_t)k);
+}
+
 static bool needs_acc(size_t k, int S) {
-  const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k);
+  const int L = bits_for_k(k);
+  if (L == 0) return false;
   return S > SINGLE_PASS_MAX_S || k > max_k_per_pass(S, L);
 }
 
@@ -586,7 +593,7 @@ int ozimmu_hip_gemm_f32(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_o
   static sgemm_t sgemm = (sgemm_t)vendor_symbol("rocblas_sgemm");
   static cgemm_t cgemm = (cgemm_t)vendor_symbol("rocblas_cgemm");
   if (!create || !set_stream || !sgemm || !cgemm) return 3;
-  std::lock_guard<std::mutex> lock(h->mtx);
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
   if (!h->rocblas_handle) {
     rocblas_handle rh = nullptr;
     if (create(&rh) != rocblas_status_success) return 3;
@@ -637,7 +644,7 @@ int ozimmu_hip_gemm_f32(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_o
 static int mantissa_loss_impl(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
                               size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb, bool cplx,
                               uint64_t counters[16]) {
-  std::lock_guard<std::mutex> lock(h->mtx);
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
   const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/split.cu:461
   const int parts = cplx ? 2 : 1;
   const size_t ea = align256(4 * m), eb = align256(4 * n), exps_bytes = parts * (ea + eb);
@@ -728,7 +735,7 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
                                                   lda, (const double *)b, ldb, (const double *)beta, (double *)c, ldc);
     return st == 0 ? 0 : 3;
   }
-  std::lock_guard<std::mutex> lock(h->mtx);
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
   if (cplx)
     return gemm_int8_complex(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a, lda, (const double *)b,
                              ldb, (const double *)beta, (double *)c, ldc, S);
@@ -741,7 +748,7 @@ int ozimmu_hip_diagonal_sums(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
                              unsigned num_split, int32_t *out) {
   if (!h || !out || num_split < 3 || num_split > 18 || m == 0 || n == 0 || k == 0) return 1;
   if (check_gemm_shape(op_A, m, k, lda, "A") | check_gemm_shape(op_B, k, n, ldb, "B")) return 1;
-  std::lock_guard<std::mutex> lock(h->mtx);
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
   return gemm_int8_real(h, op_A, op_B, m, n, k, 1.0, a, lda, b, ldb, 0.0, nullptr, m, (int)num_split, out);
 }
 
@@ -754,7 +761,7 @@ int ozimmu_hip_split_int8(ozimmu_hip_handle_t h, int8_t *out_ptr, uint32_t ldo, 
   const OperandView v = matrix == OZIMMU_MATRIX_A ? view_A(op, m, n, in_ptr, ld) : view_B(op, m, n, in_ptr, ld);
   if (ldo < v.K) return 1;
   if (v.rows == 0) return 0;
-  std::lock_guard<std::mutex> lock(h->mtx);
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
   const size_t exps_bytes = align256(4 * v.rows);
   const size_t plane_bytes = tiled_plane_bytes(v.rows, v.K, (int)num_split);
   WorkspaceUse use(h);

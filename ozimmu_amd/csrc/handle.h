@@ -45,7 +45,10 @@ struct ozimmu_hip_handle {
   // private vendor BLAS handle for the `dgemm` mode (src/handle.hpp:8), created lazily
   void *rocblas_handle = nullptr;
 
-  std::mutex mtx; // the reference is not thread safe (one unguarded global handle, src/cublas.cu:58)
+  // The reference is not thread safe (one unguarded global handle, src/cublas.cu:58).  Every entry point that touches
+  // the stream, the workspace or the private vendor handle holds this lock for the whole enqueue; recursive because
+  // the entry points call each other (auto mode -> gemm, gemm -> reallocate_working_memory, ...).
+  std::recursive_mutex mtx;
 };
 
 namespace ozhip {

@@ -15,7 +15,8 @@ struct SliceGemmArgs {
   uint32_t KB;            // k-blocks per row-block in the planes
   uint32_t kb0, kb1;      // k-block range of this pass (INT32-overflow chunking)
   uint32_t M, N;
-  uint32_t tiles_m, tiles_n; // 64x64 output tiles
+  uint32_t tiles_m, tiles_n; // output tiles of the launch (filled in by launch_slice_gemm)
+  uint32_t tiles_m2;         // wide kernel: rows of tiles one block lower, below the tiles_m full-height rows
   int L;                     // bits per slice (get_bits_per_int8)
   const double *ea;          // [M] 2^(e_max+1) per row of op(A)
   const double *eb;          // [N] per column of op(B)
@@ -31,8 +32,7 @@ struct SliceGemmArgs {
   uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue
-  unsigned long long *trace; // development only: per-phase stamps of tools/slice_gemm_pp_kernel.h
-  uint32_t trace_block0;     // first traced workgroup id
+  uint32_t rba; // row-blocks held by the A planes (filled in by launch_slice_gemm: rows are padded to TILE_ROWS)
 };
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);

@@ -22,10 +22,41 @@
 // register the 32 lanes of a half-wave store 32 consecutive doubles of column-major C (256 B runs).
 //
 // Roofline: MFMA INT8 (dense 1024 MAC/clk/SIMD).  Algorithmic work per launch: P*2*M*N*K ops.
-#include "slice_gemm_kernel.h"
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+
+#include "slice_gemm_w_kernel.h"
 
 namespace ozhip {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one bit per device id and kernel
+// instantiation (a process may drive several GPUs through one copy of this library).
+template <class K>
+static hipError_t allow_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
+static int cu_count() { // CUs of the current device (cached per device id)
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+// ---- classic kernel: 64x64 (or 128x64) workgroups, two waves per SIMD ----------------------------------------------
 template <int S, int D0, int ND, int FORCE_WM = 0>
 static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
@@ -42,16 +73,117 @@ static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   SliceGemmArgs a = a0;
   a.tiles_m = (a.M + 32 * WM - 1) / (32 * WM);
   a.tiles_n = (a.N + 63) / 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>, lds, attr_done)) return e;
   const uint32_t nb = a.tiles_m * a.tiles_n;
   hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>), dim3(nb), dim3(128 * WM), lds, stream, a);
   return hipGetLastError();
+}
+
+// ---- wide kernel: one 4-wave workgroup per CU, (32*WA) x 128 tiles (slice_gemm_w_kernel.h) ------------------------
+// WA: as many blocks per wave as the 512-entry register file holds next to the B fragments, the ring and addressing;
+// NA: 3 A buffers (prefetch distance 2) when the LDS allows, else 2.
+template <int S, int D0, int ND>
+struct WideCfg {
+  static constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
+  static constexpr bool regs_ok(int wa) { return wa * ND * 16 + SL * 4 + 16 + 14 <= 512; }
+  static constexpr size_t lds(int wa, int na) { return (size_t)(na * wa + 8) * SL * FRAG_BYTES; }
+  static constexpr size_t LDS_MAX = 160 * 1024;
+  static constexpr int WA = (regs_ok(4) && lds(4, 2) <= LDS_MAX)   ? 4
+                            : (regs_ok(3) && lds(3, 2) <= LDS_MAX) ? 3
+                            : (regs_ok(2) && lds(2, 2) <= LDS_MAX) ? 2
+                                                                   : 0;
+  static constexpr int NA = (WA && lds(WA, 3) <= LDS_MAX) ? 3 : 2;
+  static constexpr bool ok = WA >= 2;
+};
+
+// Rows of full-height (WA blocks) and reduced (WA-1 blocks) tiles that cover `rows32` 32-row blocks with the smallest
+// makespan on `ncu` CUs.  Workgroups are dispatched in order, big tiles first, each to the first CU that frees up; a
+// tile of h blocks costs h + OVH (k loop + prologue/epilogue).  Finish times take few distinct values, so the greedy
+// assignment is simulated on (time -> CU count) buckets.
+struct WidePlan {
+  uint32_t n_big = 0, n_small = 0;
+  double makespan = 0; // in block units per CU
+  double efficiency = 0;
+};
+static double simulate_rounds(uint64_t nbig, double cbig, uint64_t nsmall, double csmall, int ncu) {
+  std::map<double, uint64_t> free_at; // time -> CUs that become free then
+  free_at[0.0] = (uint64_t)ncu;
+  double last = 0;
+  auto run = [&](uint64_t n, double c) {
+    while (n) {
+      auto it = free_at.begin();
+      const uint64_t take = n < it->second ? n : it->second;
+      const double t = it->first + c;
+      it->second -= take;
+      if (it->second == 0) free_at.erase(it);
+      free_at[t] += take;
+      if (t > last) last = t;
+      n -= take;
+    }
+  };
+  run(nbig, cbig);
+  run(nsmall, csmall);
+  return last;
+}
+static WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) {
+  constexpr double OVH = 0.06;
+  const uint32_t rows32 = (M + 31) / 32, tn = (N + 127) / 128;
+  WidePlan best;
+  const uint32_t max_small = WA > 1 ? (rows32 + (WA - 2)) / (WA - 1) : 0;
+  for (uint32_t n2 = 0; n2 <= max_small; n2++) {
+    const uint32_t covered = (uint32_t)(WA - 1) * n2;
+    const uint32_t n3 = covered >= rows32 ? 0 : (rows32 - covered + WA - 1) / WA;
+    const double t = simulate_rounds((uint64_t)n3 * tn, WA + OVH, (uint64_t)n2 * tn, WA - 1 + OVH, ncu);
+    if (best.makespan == 0 || t < best.makespan - 1e-9) {
+      best.n_big = n3;
+      best.n_small = n2;
+      best.makespan = t;
+    }
+    if (n3 == 0) break;
+  }
+  best.efficiency = (double)rows32 * tn / (best.makespan * ncu);
+  return best;
+}
+
+// The wide kernel needs enough tiles to fill the CUs (a 96x128 tile is 3x the work of a 64x64 one); below that the
+// classic kernel's smaller tiles win.  OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements).
+static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu) {
+  if (const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL")) {
+    if (!std::strcmp(e, "wide")) return true;
+    if (!std::strcmp(e, "classic")) return false;
+  }
+  const uint64_t wgs = (uint64_t)(pl.n_big + pl.n_small) * tn;
+  return wgs >= (uint64_t)ncu && pl.efficiency >= 0.80;
+}
+
+template <int S, int D0, int ND>
+static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipStream_t stream) {
+  using Cfg = WideCfg<S, D0, ND>;
+  constexpr int VARW = Cfg::NA == 3 ? VARW_NA3 : 0;
+  constexpr size_t lds = Cfg::lds(Cfg::WA, Cfg::NA);
+  SliceGemmArgs a = a0;
+  a.tiles_m = pl.n_big;
+  a.tiles_m2 = pl.n_small;
+  a.tiles_n = (a.N + 127) / 128;
+  a.rba = (uint32_t)row_blocks_padded(a.M);
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>, lds, attr_done)) return e;
+  const uint32_t nb = (a.tiles_m + a.tiles_m2) * a.tiles_n;
+  hipLaunchKernelGGL((slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>), dim3(nb), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
+// one pass over the diagonals [D0, D0 + ND): wide kernel when it fits the registers / LDS and the problem fills the
+// chip, else the classic one
+template <int S, int D0, int ND, int FORCE_WM = 0>
+static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
+  if constexpr (WideCfg<S, D0, ND>::ok) {
+    const int ncu = cu_count();
+    const WidePlan pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu);
+    if (prefer_wide(pl, (a.N + 127) / 128, ncu)) return launch_wide<S, D0, ND>(a, pl, stream);
+  }
+  return launch_one<S, D0, ND, FORCE_WM>(a, stream);
 }
 
 // S <= SINGLE_PASS_MAX_S: all S diagonals in one pass.  Larger S: two diagonal ranges, the second pass
@@ -62,19 +194,19 @@ static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
     if constexpr (S <= 6) {
       // few slices = few MFMAs per staged byte: the 128x64 8-wave workgroup (-25 % staged bytes) wins once there
       // are enough tiles to fill the chip (4096^3: S=3 +8 %, S=4 +18 %, S=5 +10 %, S=6 +7 %; S=7 +1 %, S=8 -2 %)
-      if ((size_t)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 512) return launch_one<S, 0, S, 4>(a, stream);
+      if ((size_t)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 512) return launch_pass<S, 0, S, 4>(a, stream);
     }
-    return launch_one<S, 0, S>(a, stream);
+    return launch_pass<S, 0, S>(a, stream);
   } else {
     constexpr int ND1 = (S + 1) / 2, ND2 = S - ND1;
     SliceGemmArgs a1 = a;
     a1.final = 0; // -> acc
-    hipError_t e = launch_one<S, 0, ND1>(a1, stream);
+    hipError_t e = launch_pass<S, 0, ND1>(a1, stream);
     if (e != hipSuccess) return e;
     SliceGemmArgs a2 = a;
     a2.acc_in = 1;
     if (a2.dump) a2.dump += (size_t)ND1 * a.N * a.M;
-    return launch_one<S, ND1, ND2>(a2, stream);
+    return launch_pass<S, ND1, ND2>(a2, stream);
   }
 }
 

@@ -58,53 +58,69 @@ __device__ __forceinline__ double pow2d(int e) {
 }
 
 // ---- epilogue shared by the kernels: INT32 diagonal sums -> FP64 -> C ---------------------------------------
-// acc[d] holds, in the MFMA 32x32 C/D register layout (lane&31 = m, 16 registers = 16 different n), the sum of
-// the slice products with i+j = D0+d.  m: this lane's row of C; nbase: column of register 0.
-template <int D0, int ND>
-__device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, const v16i (&acc)[ND], uint32_t m,
+// acc[a][d] holds, in the MFMA 32x32 C/D register layout (lane&31 = m, 16 registers = 16 different n), the sum of
+// the slice products with i+j = D0+d of the a-th 32-row block of the wave (rows m0 + 32*a + (lane&31)).
+// m0: this lane's row of C in block 0; nbase: column of register 0.  The loop runs over the 16 registers (columns)
+// outermost so that everything that depends on n only is computed once and dies before the next column: the wide
+// kernel (slice_gemm_w_kernel.h) arrives here with up to 432 live accumulator registers.
+// acc(a, d, r): register r of diagonal accumulator d of block a (all three are compile-time constants after unrolling).
+template <int D0, int ND, int WA, class Acc>
+__device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, const Acc &acc, uint32_t m0,
                                                     uint32_t nbase) {
   if (p.dump) { // test hook: raw INT32 diagonal sums, [ND][N][M]
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
-      if (m < p.M && n < p.N)
 #pragma unroll
-        for (int d = 0; d < ND; d++) p.dump[((size_t)d * p.N + n) * p.M + m] = acc[d][r];
+      for (int a = 0; a < WA; a++) {
+        const uint32_t m = m0 + 32 * a;
+        if (m < p.M && n < p.N)
+#pragma unroll
+          for (int d = 0; d < ND; d++) p.dump[((size_t)d * p.N + n) * p.M + m] = acc(a, d, r);
+      }
     }
     if (p.dump_only) return;
   }
   double sc[ND];
 #pragma unroll
   for (int d = 0; d < ND; d++) sc[d] = pow2d(46 - p.L * (D0 + d + 2));
-  const bool mok = m < p.M;
-  const double ea = mok ? p.ea[m] : 0.0;
+  double ea[WA];
+#pragma unroll
+  for (int a = 0; a < WA; a++) ea[a] = (m0 + 32 * a < p.M) ? p.ea[m0 + 32 * a] : 0.0;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
+    __builtin_amdgcn_sched_barrier(0); // keep the per-column work from being hoisted over the live accumulators
     const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
-    if (!mok || n >= p.N) continue;
-    double x = p.acc_in ? p.acc[(size_t)n * p.M + m] : 0.0;
+    if (n >= p.N) continue;
+    const double ebn = p.final ? p.eb[n] : 0.0;
 #pragma unroll
-    for (int d = 0; d < ND; d++) x = fma((double)acc[d][r], sc[d], x);
-    if (!p.final) {
-      p.acc[(size_t)n * p.M + m] = x;
-    } else {
-      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
-      const double v = x * 0x1p-44 * ea * p.eb[n];
-      if (p.cplx) {
-        // one of the four real products of a ZGEMM: C += (alpha_re + i alpha_im) * v  (axy_complex_kernel,
-        // src/gemm.cu:160-186; C was scaled by beta beforehand, src/gemm.cu:199-239)
-        double2 *zp = reinterpret_cast<double2 *>(p.c) + ((size_t)n * p.ldc + m);
-        double2 y = *zp;
-        y.x = fma(p.alpha, v, y.x);
-        y.y = fma(p.alpha_im, v, y.y);
-        *zp = y;
-        continue;
+    for (int a = 0; a < WA; a++) {
+      const uint32_t m = m0 + 32 * a;
+      if (m >= p.M) continue;
+      double x = p.acc_in ? p.acc[(size_t)n * p.M + m] : 0.0;
+#pragma unroll
+      for (int d = 0; d < ND; d++) x = fma((double)acc(a, d, r), sc[d], x);
+      if (!p.final) {
+        p.acc[(size_t)n * p.M + m] = x;
+      } else {
+        // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
+        const double v = x * 0x1p-44 * ea[a] * ebn;
+        if (p.cplx) {
+          // one of the four real products of a ZGEMM: C += (alpha_re + i alpha_im) * v  (axy_complex_kernel,
+          // src/gemm.cu:160-186; C was scaled by beta beforehand, src/gemm.cu:199-239)
+          double2 *zp = reinterpret_cast<double2 *>(p.c) + ((size_t)n * p.ldc + m);
+          double2 y = *zp;
+          y.x = fma(p.alpha, v, y.x);
+          y.y = fma(p.alpha_im, v, y.y);
+          *zp = y;
+          continue;
+        }
+        double *cp = p.c + (size_t)n * p.ldc + m;
+        if (p.beta != 0.0)
+          *cp = fma(p.alpha, v, p.beta * *cp);
+        else
+          *cp = p.alpha * v;
       }
-      double *cp = p.c + (size_t)n * p.ldc + m;
-      if (p.beta != 0.0)
-        *cp = fma(p.alpha, v, p.beta * *cp);
-      else
-        *cp = p.alpha * v;
     }
   }
 }
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemm
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
-  recombine_and_store<D0, ND>(p, acc, tm * (32 * WM) + wm * 32 + (lane & 31), tn * 64 + wn * 32 + 4 * (lane >> 5));
+  recombine_and_store<D0, ND, 1>(p, [&](int, int d, int r) { return acc[d][r]; }, tm * (32 * WM) + wm * 32 + (lane & 31), tn * 64 + wn * 32 + 4 * (lane >> 5));
 }
 
 } // namespace ozhip

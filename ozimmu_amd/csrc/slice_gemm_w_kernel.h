@@ -1,0 +1,409 @@
+// slice_gemm_w_kernel.h — "wide" form of the fused INT8 slice GEMM: ONE 4-wave workgroup per CU, one wave per SIMD,
+// each wave owning WA vertically stacked 32x32 output blocks whose S INT32 diagonal accumulators fill the unified
+// 512-entry VGPR+AGPR file (WA*ND*16 registers: 432 at S=9, WA=3).
+//
+// Why: the part is power-limited under full-entropy INT8 MFMA, and everything that is not an MFMA
+// (HBM/L2 -> LDS copies, LDS fragment reads) costs both stall time and clock.  The register file bounds the outputs a
+// CU can keep resident; with two waves per SIMD (slice_gemm_kernel.h) each wave can hold one 32x32 block at S=9
+// (8 192 outputs per CU), with one wave per SIMD three (12 288 outputs per CU).  Tile = (32*WA) x 128:
+//
+//                               staged KiB per wave-MFMA      LDS fragment reads per MFMA
+//   2 x (64x64, 4 waves)             0.200 * S                       0.40
+//   1 x (96x128, 4 waves, WA=3)      0.117 * S   (-42 %)             0.27   (-33 %)
+//
+//   * the WA A row-blocks are shared by the 4 waves (staged cooperatively, one barrier per k-step); every wave has
+//     its own B row-block, staged by that wave alone: wave-private LDS, ordered by the wave's own vmcnt only;
+//   * NA A-buffers (prefetch distance NA-1) and 2 B-buffers.  The B fragments of a k-step are copied to registers at
+//     the top of the step, so the B buffer can be refilled (distance 2) as soon as those reads have returned;
+//   * A fragments stream through a small register ring, the LDS-DMA copies of the stage being prefetched are spread
+//     between the MFMA groups so that no copy waits behind another wave's burst in the CU's texture-address queue.
+//
+// Same arithmetic as slice_gemm_kernel (same diagonal accumulators, same epilogue): results are bit-identical.
+#pragma once
+#include <type_traits>
+
+#include "slice_gemm_kernel.h"
+
+namespace ozhip {
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, F, I + 1>(static_cast<F &&>(f));
+  }
+}
+
+// c += b (32 rows x 32 k, MFMA "A" operand) * a (MFMA "B" operand), accumulator pinned to the AGPR / VGPR half
+__device__ __forceinline__ void mfma_agpr(v16i &c, const v4i &b, const v4i &a) {
+  asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
+}
+__device__ __forceinline__ void mfma_vgpr(v16i &c, const v4i &b, const v4i &a) {
+  asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(c) : "v"(b), "v"(a));
+}
+
+// one 1 KiB fragment block HBM/L2 -> LDS: lane l copies 16 bytes from sbase + voff(l) + IMM to LDS lds_dst + IMM + 16*l.
+// sbase and lds_dst are wave-uniform (SGPRs).  M0 carries the LDS base; it is compiler-reserved, so it is saved and
+// restored inside the statement (guide §5.7); s_nop 0: s_mov m0 -> LDS-DMA needs one wait state.
+template <int IMM>
+__device__ __forceinline__ void glds16(const int8_t *sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%c4\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM)
+               : "memory");
+}
+
+// MFMA slots of one k-step of a wave that owns WA blocks: block a outermost, A slice i ascending, B slice j descending
+// over the pairs with D0 <= i + j < D0 + ND, i + j <= S - 1
+template <int S, int D0, int ND, int WA>
+struct WSched {
+  static constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
+  static constexpr int MAXS = WA * SL * SL, MAXG = WA * SL;
+  int ns = 0, ng = 0;
+  int sa[MAXS] = {}, si[MAXS] = {}, sj[MAXS] = {}, sg[MAXS] = {};
+  int gfirst[MAXG] = {}, g_a[MAXG] = {}, g_i[MAXG] = {};
+  constexpr WSched() {
+    for (int a = 0; a < WA; a++)
+      for (int i = 0; i < SL; i++) {
+        bool any = false;
+        for (int j = SL - 1; j >= 0; j--) {
+          const int d = i + j;
+          if (d < D0 || d >= D0 + ND || d > S - 1) continue;
+          if (!any) {
+            gfirst[ng] = ns;
+            g_a[ng] = a;
+            g_i[ng] = i;
+            any = true;
+          }
+          sa[ns] = a; si[ns] = i; sj[ns] = j; sg[ns] = ng;
+          ns++;
+        }
+        if (any) ng++;
+      }
+  }
+  constexpr int max_j_from(int s0) const {
+    int m = 0;
+    for (int s = s0; s < ns; s++) m = sj[s] > m ? sj[s] : m;
+    return m;
+  }
+  // last slot in [from, ns) ... of the FIRST group that uses a B slice j < jt (the first group runs j descending)
+  constexpr int last_use_of_j_below(int jt, int group) const {
+    int last = 0;
+    for (int s = 0; s < ns; s++)
+      if (sg[s] == group && sj[s] < jt) last = s;
+    return last;
+  }
+};
+
+template <int S, int D0, int ND, int WA>
+inline constexpr WSched<S, D0, ND, WA> kWSched{};
+
+// VARW bits
+constexpr int VARW_NA3 = 1;        // 3 A buffers (prefetch distance 2); else 2 (distance 1)
+constexpr int VARW_NO_GLOBAL = 2;  // ablation: no staging (LDS holds garbage)
+constexpr int VARW_MFMA_ONLY = 4;  // ablation: no LDS reads either
+
+// One output tile of (32*WA) x 128: rows start at A row-block rb0, columns at B row-block 4*tn.
+template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0_, int DMAE_, int TAIL_>
+__device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const uint32_t rb0, const uint32_t tn) {
+  constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
+  constexpr int NA = (VARW & VARW_NA3) ? 3 : 2;
+  constexpr int PD = NA - 1;                       // prefetch distance in k-steps
+  constexpr int A_STAGE = WA * SL * FRAG_BYTES;    // shared
+  constexpr int B_STAGE = 4 * SL * FRAG_BYTES;     // 4 wave-private runs of SL blocks
+  constexpr int OFF_B = NA * A_STAGE;
+  constexpr int NQA = (WA * SL + 3) / 4;           // A blocks copied per wave per stage
+  constexpr int NDMA = NQA + SL;                   // copies per wave per stage
+  constexpr int R = 4;                             // A fragment ring (registers)
+  constexpr int NG = WA * SL;                      // MFMA groups per k-step: one per (A block, A slice)
+  constexpr bool NO_GLOBAL = (VARW & (VARW_NO_GLOBAL | VARW_MFMA_ONLY)) != 0;
+  constexpr bool MFMA_ONLY = (VARW & VARW_MFMA_ONLY) != 0;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // ---- staging -------------------------------------------------------------------------------------------------
+  // A stage: WA*SL blocks numbered q = a*SL + s; wave w copies the run q = w*NQA .. w*NQA+NQA-1 (clamped: the last
+  // wave repeats the final block, so every wave issues the same number of copies and the vmcnt arithmetic is uniform).
+  const size_t rb_stride = (size_t)p.KB * (size_t)(S * FRAG_BYTES);
+  const uint32_t rba_last = p.rba - 1u; // row-blocks the planes hold (rows are padded to 128, tiles to 32*WA)
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  const int8_t *a_src[NQA];
+  uint32_t a_q[NQA];
+#pragma unroll
+  for (int t = 0; t < NQA; t++) {
+    uint32_t q = (uint32_t)(wave * NQA + t);
+    if (q > (uint32_t)(WA * SL - 1)) q = WA * SL - 1;
+    const uint32_t a = q / SL, s = q - a * SL;
+    uint32_t rb = rb0 + a;
+    if (rb > rba_last) rb = rba_last;
+    a_src[t] = p.a_planes + rb * rb_stride + s * FRAG_BYTES;
+    a_q[t] = q;
+  }
+  const int8_t *b_src = p.b_planes + (size_t)(4u * tn + wave) * rb_stride;
+
+  // The copies are inline asm (glds16): hipcc counts an LDS-DMA builtin on BOTH vmcnt and lgkmcnt, after which every
+  // wait it places in front of a fragment's first use is lgkmcnt(0) -- draining the ring read issued just before it
+  // (measured in the ISA: 18 x lgkmcnt(0) per k-step instead of counted lgkmcnt(3)).  Invisible to the compiler, the
+  // copies are ordered by the explicit counted vmcnt waits below.
+  const uint32_t lds0 = (uint32_t)(size_t)((OZ_AS3 char *)smem);
+  auto copy_a = [&](int t, int buf, uint32_t kb) {
+    if constexpr (NO_GLOBAL) return;
+    glds16<0>(a_src[t] + (size_t)kb * (S * FRAG_BYTES), lane_off, lds0 + buf * A_STAGE + a_q[t] * FRAG_BYTES);
+  };
+  auto copy_b = [&](auto sc, int buf, uint32_t kb) {
+    if constexpr (NO_GLOBAL) return;
+    constexpr int s = decltype(sc)::value;
+    constexpr int G = 3; // immediate-offset groups (the offset also advances the LDS address)
+    constexpr int g0 = s / G * G;
+    const int8_t *gu = b_src + (size_t)kb * (S * FRAG_BYTES) + g0 * FRAG_BYTES;
+    const uint32_t l = lds0 + OFF_B + (buf * 4 + wave) * (SL * FRAG_BYTES) + g0 * FRAG_BYTES;
+    glds16<(s % G) * FRAG_BYTES>(gu, lane_off, l);
+  };
+  // copy number c (0..NDMA-1) of a stage: A share first (the other waves wait for it), then the private B run
+  auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kb) {
+    constexpr int c = decltype(cc)::value;
+    if constexpr (c < NQA)
+      copy_a(c, abuf, kb);
+    else
+      copy_b(std::integral_constant<int, c - NQA>{}, bbuf, kb);
+  };
+
+  // ---- accumulators: WA*ND x 16 registers, placed by hand ---------------------------------------------------------
+  // The unified file gives a lone wave 256 VGPRs + 256 AGPRs.  hipcc's MFMA builtin wants every accumulator in ONE of
+  // the two halves and shuffles the excess through v_accvgpr copies and scratch; inline-asm MFMAs with explicit register
+  // classes pin accumulators 0..15 to the AGPR half and the rest to VGPRs.  Hazards the compiler no longer pads
+  // (guide §5.7): MFMA -> MFMA on the same accumulator needs no wait state; the first MFMA after the zero-fill and the
+  // first VALU read after the last MFMA are covered by the s_nop statements below.
+  constexpr int NACC = WA * ND, NACC_A = NACC < 16 ? NACC : 16, NACC_V = NACC > 16 ? NACC - 16 : 1;
+  v16i accA[NACC_A], accV[NACC_V];
+#pragma unroll
+  for (int x = 0; x < NACC_A; x++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) accA[x][r] = 0;
+#pragma unroll
+  for (int x = 0; x < NACC_V; x++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) accV[x][r] = 0;
+  auto mfma = [&](auto xc, const v4i &b, const v4i &a) {
+    constexpr int X = decltype(xc)::value;
+    if constexpr (X < 16)
+      mfma_agpr(accA[X], b, a);
+    else
+      mfma_vgpr(accV[X - 16], b, a);
+  };
+
+  // ---- circular K with the per-XCD phase hint (slice_gemm_kernel.h) ----------------------------------------------
+  const uint32_t nk = p.kb1 - p.kb0;
+  uint32_t *phase = p.phase ? p.phase + 64u * (blockIdx.x & 7u) : nullptr;
+  uint32_t koff = 0;
+  if (phase && nk > 1) {
+    if (threadIdx.x == 0)
+      *(volatile uint32_t *)smem = __hip_atomic_load(phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    koff = (*(volatile uint32_t *)smem + 2u) % nk;
+    __syncthreads();
+  }
+  koff = __builtin_amdgcn_readfirstlane(koff);
+  auto koff_next = [&](uint32_t k) { return k + 1 == nk ? 0u : k + 1; };
+
+  v4i cf[MFMA_ONLY ? SL : 1]; // MFMA-only ablation: full-entropy operands in registers
+  if constexpr (MFMA_ONLY) {
+#pragma unroll
+    for (int s = 0; s < SL; s++) {
+      uint32_t x = (uint32_t)(lane * SL + s) * 2654435761u + blockIdx.x;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+        cf[s][c] = (int)x;
+      }
+      asm volatile("" : "+v"(cf[s]));
+    }
+  }
+
+  // ---- schedule of one k-step (compile time) ---------------------------------------------------------------------
+  // SC lists the MFMA slots of a k-step: block a outermost, A slice i ascending, B slice j descending; a "group" is the
+  // run of slots that share one A fragment (a, i).  Events are attached to slots:
+  //   * first slot of group g: read the A fragment of group g+R-1 into ring slot (g+R-1) % R (the slot of group g-1);
+  //     the group sequence is padded with empty groups to a multiple of R (NGP) so that the ring position of a group
+  //     is the same in every k-step and the prefetch runs across the step boundary into the next stage's buffer;
+  //   * slots DMA0, DMA0+DMAE, ...: one LDS-DMA copy of the stage PD steps ahead (A share first, then the private B);
+  //   * slot NS-TAIL ("X"): wait for the own copies of the NEXT stage, barrier, then refresh bf[JT..] from it; the TAIL
+  //     remaining MFMAs of this step use bf[0..JT-1] only and cover the barrier and the LDS latency; bf[0..JT-1] are
+  //     refreshed behind the last MFMA and are needed last in the next step's first group (j descending).
+#define SC (kWSched<S, D0, ND, WA>) /* namespace-scope constexpr object: usable inside the lambdas below */
+  constexpr int NS = SC.ns;
+  constexpr int NGP = (NG + R - 1) / R * R;
+  constexpr int TAIL = TAIL_ < NS ? TAIL_ : NS - 1;
+  constexpr int XS = NS - TAIL;
+  constexpr int DMA0 = DMA0_ >= 0 ? DMA0_ : SC.gfirst[1 < NG ? 1 : 0]; // default: behind the first group
+  constexpr int DMAE_FIT = NDMA > 1 ? (XS - 1 - DMA0) / (NDMA - 1) : 1;
+  constexpr int DMAE = DMAE_ < DMAE_FIT ? DMAE_ : (DMAE_FIT > 1 ? DMAE_FIT : 1);
+  constexpr int JT = SC.max_j_from(XS) + 1; // B slices still needed after X
+  static_assert(SC.ng == NG, "empty (a, i) groups are not supported by the ring arithmetic");
+  static_assert(NGP - (R - 1) >= NG || SC.gfirst[NGP - (R - 1) < NG ? NGP - (R - 1) : 0] >= XS,
+                "the first fragment read of the next stage must come after the barrier");
+  static_assert(DMA0 + (NDMA - 1) * DMAE < XS, "every copy of a stage is issued before the barrier slot");
+  static_assert(PD == 1 || DMA0 + NQA * DMAE >= SC.last_use_of_j_below(JT, 0) + 1,
+                "distance 2: the B copies overwrite the buffer bf[0..JT-1] were read from at the end of the last step");
+
+  const char *la0 = smem + lane * 16;
+  const char *lb0 = smem + OFF_B + wave * (SL * FRAG_BYTES) + lane * 16;
+  int abuf = 0, bbuf = 0; // buffers of the stage being computed
+  v4i bf[SL], af[R];
+  auto read_a = [&](auto gc, const char *la) { // A fragment of group g -> ring
+    constexpr int g = decltype(gc)::value;
+    af[g % R] = *(const v4i *)(la + (SC.g_a[g] * SL + SC.g_i[g]) * FRAG_BYTES);
+  };
+
+  // ---- prologue: stages 0 .. PD-1 in flight, stage 0 landed, its B fragments and first A fragments in registers --
+  uint32_t k_issue = koff;
+  int issued = 0;
+#pragma unroll
+  for (int d = 0; d < PD; d++) {
+    if ((uint32_t)d < nk) {
+      static_for<NDMA>([&](auto cc) { copy_n(cc, d % NA, d % 2, p.kb0 + k_issue); });
+      k_issue = koff_next(k_issue);
+      issued++;
+    }
+  }
+  if constexpr (!NO_GLOBAL) {
+    if (issued == 2)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if constexpr (!MFMA_ONLY) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb0 + j * FRAG_BYTES);
+    static_for<(R - 1 < NG ? R - 1 : NG)>([&](auto gc) { read_a(gc, la0); });
+  }
+  asm volatile("s_nop 7" ::: "memory"); // zero-fill (VALU / v_accvgpr_write) -> first MFMA reading it as C
+
+  // one k-step.  PF: a stage is prefetched during it; NX: a next stage exists (barrier + refresh at X)
+  auto step = [&](auto pf_tag, auto nx_tag) {
+    constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value;
+    const int abuf_n = abuf + 1 == NA ? 0 : abuf + 1;                        // next stage
+    const int abuf_pf = (PD == 1) ? abuf_n : (abuf_n + 1 == NA ? 0 : abuf_n + 1); // stage PD ahead
+    const int bbuf_pf = (PD == 1) ? (bbuf ^ 1) : bbuf;
+    const uint32_t kb_pf = p.kb0 + k_issue;
+    if constexpr (PF) k_issue = koff_next(k_issue);
+    const char *la = la0 + abuf * A_STAGE;
+    const char *la_n = la0 + abuf_n * A_STAGE;
+    const char *lb_n = lb0 + (bbuf ^ 1) * B_STAGE;
+    static_for<NS>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int g = SC.sg[s];
+      if constexpr (s == XS && NX && !MFMA_ONLY) {
+        if constexpr (!NO_GLOBAL) {
+          if constexpr (PF && PD > 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NDMA) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own reads of the buffer the barrier releases have returned
+        __builtin_amdgcn_s_barrier(); // A of the next stage visible; nobody reads A of this stage from LDS any more
+        asm volatile("" ::: "memory");
+        if constexpr (STAG > 0) // de-phase the 4 lockstep waves so that their copies do not queue in the TA
+          for (int q = 0; q < wave; q++) asm volatile("s_nop %0" ::"n"(STAG - 1));
+        if (phase && threadIdx.x == 0) __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int j = JT; j < SL; j++) bf[j] = *(const v4i *)(lb_n + j * FRAG_BYTES);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (SC.gfirst[g] == s && !MFMA_ONLY) {
+        constexpr int gn = g + R - 1;
+        if constexpr (gn < NG) {
+          read_a(std::integral_constant<int, gn>{}, la);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (gn >= NGP && NX) {
+          read_a(std::integral_constant<int, gn - NGP>{}, la_n);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (PF && s >= DMA0 && (s - DMA0) % DMAE == 0 && (s - DMA0) / DMAE < NDMA) {
+        copy_n(std::integral_constant<int, (s - DMA0) / DMAE>{}, abuf_pf, bbuf_pf, kb_pf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr int a = SC.sa[s], i = SC.si[s], j = SC.sj[s];
+      if constexpr (MFMA_ONLY)
+        mfma(std::integral_constant<int, a * ND + i + j - D0>{}, cf[j], cf[i]);
+      else
+        mfma(std::integral_constant<int, a * ND + i + j - D0>{}, bf[j], af[g % R]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NX && !MFMA_ONLY) {
+#pragma unroll
+      for (int j = 0; j < JT; j++) bf[j] = *(const v4i *)(lb_n + j * FRAG_BYTES);
+      // next-stage A fragments whose trigger group is one of the empty padding groups
+      static_for<R - 1>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (NGP + q - (R - 1) >= NG && q < NG) read_a(qc, la_n);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    koff = koff_next(koff);
+    abuf = abuf_n;
+    bbuf ^= 1;
+  };
+  uint32_t it = 0;
+  for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{});
+  for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{});
+  for (; it < nk; it++) step(std::false_type{}, std::false_type{});
+
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA (16 passes) -> VALU reads of its accumulator
+  auto acc = [&](int a, int d, int r) {
+    const int x = a * ND + d;
+    return x < 16 ? accA[x < 16 ? x : 0][r] : accV[x >= 16 ? x - 16 : 0][r];
+  };
+  recombine_and_store<D0, ND, WA>(p, acc, rb0 * 32 + (lane & 31), tn * 128 + wave * 32 + 4 * (lane >> 5));
+}
+
+// contiguous run of logical ids for XCD x out of n (bijective form of the guide's T1 swizzle)
+__device__ __forceinline__ uint32_t xcd_run_start(uint32_t x, uint32_t n) {
+  const uint32_t q = n >> 3, r = n & 7u;
+  return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+}
+// logical id inside a region of rows x cols tiles -> (row, col): bands of 8 rows, columns outer inside a band, so
+// that the 32 workgroups an XCD runs concurrently form an 8 (M) x 4 (N) patch that shares A and B panels in its L2
+__device__ __forceinline__ void band_order(uint32_t lid, uint32_t rows, uint32_t cols, uint32_t &r, uint32_t &c) {
+  const uint32_t band_tiles = 8u * cols, nbands = (rows + 7u) >> 3;
+  uint32_t band = lid / band_tiles;
+  if (band > nbands - 1) band = nbands - 1;
+  const uint32_t rem = lid - band * band_tiles;
+  const uint32_t h = (rows - band * 8u) < 8u ? (rows - band * 8u) : 8u;
+  c = rem / h;
+  r = band * 8u + rem % h;
+}
+
+// Grid = tiles_m x tiles_n "big" tiles of WA blocks + tiles_m2 x tiles_n "small" tiles of WA-1 blocks below them.  The
+// mix lets the host fit the row count and the number of CU rounds (8192 rows = 80 x 96 + 8 x 64: 20 + 2 full rounds
+// on 256 CUs instead of 21.5 -> 22 with 96-row tiles only).  Every XCD gets a contiguous run of each region, big
+// tiles first; the extras of the small region start at the XCD where the big region's extras stop, which makes the
+// per-XCD totals equal to what the round-robin dispatch hands each XCD.
+template <int S, int D0, int ND, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL_ = 6>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void slice_gemm_w_kernel(
+    const SliceGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t nbig = p.tiles_m * p.tiles_n, nsmall = p.tiles_m2 * p.tiles_n;
+  const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  const uint32_t nbig_x = (nbig >> 3) + (xcd < (nbig & 7u) ? 1u : 0u);
+  uint32_t r, c;
+  if (idx < nbig_x) {
+    band_order(xcd_run_start(xcd, nbig) + idx, p.tiles_m, p.tiles_n, r, c);
+    w_tile<S, D0, ND, WA, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * r, c);
+  } else {
+    if constexpr (WA > 1) {
+      band_order(xcd_run_start((xcd - (nbig & 7u)) & 7u, nsmall) + (idx - nbig_x), p.tiles_m2, p.tiles_n, r, c);
+      w_tile<S, D0, ND, WA - 1, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * p.tiles_m + (WA - 1) * r, c);
+    }
+  }
+}
+
+#undef SC
+
+} // namespace ozhip

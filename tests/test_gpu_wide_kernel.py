@@ -1,0 +1,137 @@
+"""GPU parity tests of the wide slice-GEMM kernel (slice_gemm_w_kernel.h: one 4-wave workgroup per CU, (32*WA) x 128
+tiles, accumulators split over the VGPR and AGPR halves, inline-asm MFMAs and LDS-DMA copies).
+
+The library picks this kernel only for problems that fill the chip; OZIMMU_HIP_GEMM_KERNEL=wide forces it so that the
+small, ragged shapes the oracle can check in seconds run through it too: mixed tile heights (full + reduced rows of
+tiles), rows beyond the padded planes (clamped row-blocks), one k-step, the tail steps of both prefetch distances, K
+chunking, the two diagonal passes of S >= 13, and the complex path.  Same bar as test_gpu_parity.py: INT32 diagonal sums
+and the FP64 result bit-exact vs the oracle (OZ_ORDER_DIAGONAL)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import ColMajor, exp_rand, operand, uniform_pm1, wide_exponent
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def force_wide(monkeypatch):
+    monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", "wide")
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+# every S has its own instantiation (WA = 4 for S <= 7, 3 for 8..9, 2 for 10..12; S = 13: 4 + 2; S >= 14: first pass)
+@pytest.mark.parametrize("S", list(range(3, 19)))
+@pytest.mark.parametrize("m,n,k", [(97, 129, 65), (300, 140, 200)])
+def test_wide_diagonal_sums_bit_exact(oz, S, m, n, k):
+    import torch
+    m_, h = oz
+    rng = np.random.default_rng(m * 7 + n * 3 + k + S)
+    a = operand("N", m, k, rng, fill=exp_rand(2.0))
+    b = operand("T", k, n, rng, fill=exp_rand(2.0))
+    L = O.bits_per_int8(k)
+    pa, _ = O.split("A", "N", a.view, S, L)
+    pb, _ = O.split("B", "T", b.view, S, L)
+    d_ref = O.diagonal_sums(pa, pb)  # [S][m][n] int64
+    out = torch.full((S, n, m), 12345, dtype=torch.int32, device="cuda")
+    assert m_.diagonal_sums(h, "N", "T", m, n, k, a.dev, a.ld, b.dev, b.ld, S, out) == 0
+    _sync()
+    np.testing.assert_array_equal(out.cpu().numpy().transpose(0, 2, 1).astype(np.int64), d_ref)
+
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (64, 64, 32), (96, 128, 64), (97, 129, 33), (200, 130, 96),
+                                   (389, 257, 130), (1000, 200, 70)])
+@pytest.mark.parametrize("S", [4, 8, 9, 11, 13, 16])
+def test_wide_gemm_bit_exact_vs_oracle(oz, op_a, op_b, m, n, k, S):
+    m_, h = oz
+    rng = np.random.default_rng(m + 2 * n + 3 * k + S)
+    a = operand(op_a, m, k, rng, pad=1)
+    b = operand(op_b, k, n, rng, pad=2)
+    c = ColMajor(m, n, ld=m + 3, fill=uniform_pm1, rng=rng)
+    c_ref = ColMajor(m, n, ld=m + 3)
+    c_ref.buf[...] = c.buf
+    st = m_.gemm(h, op_a, op_b, m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, f"fp64_int8_{S}")
+    _sync()
+    assert st == 0
+    assert O.gemm(op_a, op_b, m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+    assert np.isnan(c.buf[:, m:]).all()  # ld padding untouched
+
+
+@pytest.mark.parametrize("alpha,beta", [(-2.5, 0.0), (1.0, 1.0), (0.75, -1.25)])
+def test_wide_gemm_alpha_beta(oz, alpha, beta):
+    m_, h = oz
+    m, n, k, S = 230, 190, 160, 9
+    rng = np.random.default_rng(5)
+    a = operand("N", m, k, rng, fill=wide_exponent(4))
+    b = operand("T", k, n, rng)
+    c = ColMajor(m, n, fill=uniform_pm1, rng=rng)
+    c_ref = ColMajor(m, n)
+    c_ref.buf[...] = c.buf
+    assert m_.gemm(h, "N", "T", m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, "fp64_int8_9") == 0
+    _sync()
+    assert O.gemm("N", "T", m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
+@pytest.mark.parametrize("S", [9, 14])
+def test_wide_gemm_k_chunking(oz, S):
+    """K above the INT32-safe pass length: chained passes through the FP64 acc workspace (and, for S = 14, the two
+    diagonal passes: the first on the wide kernel, the second on the classic one)"""
+    m_, h = oz
+    m, n, k = 100, 130, 20000
+    rng = np.random.default_rng(3 + S)
+    a = operand("N", m, k, rng)
+    b = operand("N", k, n, rng)
+    c = ColMajor(m, n)
+    c_ref = ColMajor(m, n)
+    assert m_.gemm(h, "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, f"fp64_int8_{S}") == 0
+    _sync()
+    kchunk = (2147483647 // (S * 127 * 127)) // 32 * 32
+    O.gemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL, kchunk=kchunk)
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
+def test_wide_equals_classic_bitwise_on_a_chip_filling_problem(oz, monkeypatch):
+    """2048 x 1536 x 1024 (fills 256 CUs with mixed-height tiles): the two kernels give the same bits"""
+    import torch
+    m_, h = oz
+    m, n, k = 2048, 1536, 1024
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.rand(k, m, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    b = torch.rand(n, k, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    out = {}
+    for which in ("wide", "classic"):
+        monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", which)
+        c = torch.full((n, m), float("nan"), dtype=torch.float64, device="cuda")
+        assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c, m, "fp64_int8_9") == 0
+        _sync()
+        out[which] = c
+    assert torch.equal(out["wide"].view(torch.int64), out["classic"].view(torch.int64))
+    ref = (b @ a)  # row-major view of the column-major product
+    assert ((out["wide"] - ref).norm() / ref.norm()).item() < 1e-14
+
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "T")])
+def test_wide_zgemm_bit_exact(oz, op_a, op_b):
+    from tests.test_gpu_zgemm import zbits, zoperand
+    m_, h = oz
+    m, n, k, S = 130, 140, 96, 9
+    rng = np.random.default_rng(17)
+    a = zoperand(op_a, m, k, rng, "wide", pad=1)
+    b = zoperand(op_b, k, n, rng, "wide")
+    c = zoperand("N", m, n, rng, pad=3)
+    c_ref = ColMajor(m, n, ld=m + 3, dtype=np.complex128)
+    c_ref.buf[...] = c.buf
+    alpha, beta = 0.5 - 1.5j, 0.25 + 0.75j
+    st = m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, "fp64_int8_9", m_.complx)
+    _sync()
+    assert st == 0
+    assert O.zgemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    np.testing.assert_array_equal(zbits(c.download()), zbits(c_ref.view))

@@ -11,7 +11,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "slice_gemm_pp_kernel.h" // tools/: experiment, not part of the library
+#include "slice_gemm_w_kernel.h"
 
 using namespace ozhip;
 
@@ -66,23 +66,27 @@ static float run_throttled(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e
   return run<S, VAR>(a, st, e0, e1);
 }
 
-template <int S, int VAR>
-static float run_pp(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  constexpr size_t lds = 2 * 6 * S * FRAG_BYTES + ((VAR & 1) ? 8192 : 0);
+// wide kernel (one 4-wave workgroup per CU, WA blocks per wave)
+template <int S, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL = 6>
+static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  constexpr int NA = (VARW & VARW_NA3) ? 3 : 2;
+  constexpr size_t lds = (size_t)(NA * WA + 2 * 4) * S * FRAG_BYTES;
   SliceGemmArgs a = a0;
-  a.tiles_m = (a.M + 63) / 64;
+  a.tiles_m = (a.M + 32 * WA - 1) / (32 * WA);
   a.tiles_n = (a.N + 127) / 128;
+  a.rba = (uint32_t)row_blocks_padded(a.M);
   static bool done = false;
   if (!done) {
-    CK(hipFuncSetAttribute((const void *)slice_gemm_pp_kernel<S, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CK(hipFuncSetAttribute((const void *)slice_gemm_w_kernel<S, 0, S, WA, VARW, STAG, DMA0, DMAE, TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)lds));
     done = true;
   }
   CK(hipMemsetAsync(a.phase, 0, 8 * 256, st));
   CK(hipEventRecord(e0, st));
-  hipLaunchKernelGGL((slice_gemm_pp_kernel<S, VAR>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((slice_gemm_w_kernel<S, 0, S, WA, VARW, STAG, DMA0, DMAE, TAIL>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   return ms;
@@ -92,7 +96,7 @@ int main(int argc, char **argv) {
   const size_t N = argc > 1 ? std::atol(argv[1]) : 8192;
   const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
   constexpr int S = 9;
-  const size_t M = N, K = N;
+  const size_t M = argc > 4 ? std::atol(argv[4]) : N, K = argc > 5 ? std::atol(argv[5]) : N;
   const size_t pa = tiled_plane_bytes(M, K, S), pb = tiled_plane_bytes(N, K, S);
   int8_t *A, *B;
   double *ea, *eb, *C;
@@ -144,74 +148,44 @@ int main(int argc, char **argv) {
     std::vector<float> ms;
   };
   std::vector<Var> vars = {
-      {"shipped 64x64", run<S, VAR_SHIPPED>, false, {}},
-      {"ping-pong 64x128", run_pp<S, 0>, false, {}},
-      {"ping-pong 64x128 MUBUF", run_pp<S, 2>, false, {}},
-      {"shipped + lead throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
-      {"prefetch-1 loop (as S >= 11)", run_throttled<S, VAR_SHIPPED & ~VAR_PF2>, false, {}},
-      {"throttle, plain patch order", run_throttled<S, VAR_SHIPPED | VAR_NO_CU_SWIZZLE>, false, {}},
-      {"shipped, L2-hot addresses", run<S, VAR_SHIPPED | VAR_HOT>, false, {}},
-      {"shipped, L1-hot addresses", run<S, VAR_SHIPPED | VAR_HOT1>, false, {}},
+      {"shipped 64x64 + throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
+      {"wide 96x128 pd2", run_w<S, 3, VARW_NA3>, false, {}},
+      {"wide 96x128 pd2 stag16", run_w<S, 3, VARW_NA3, 16>, false, {}},
+      {"wide 96x128 pd2 stag8", run_w<S, 3, VARW_NA3, 8>, false, {}},
+      {"wide 96x128 pd2 dma every 2", run_w<S, 3, VARW_NA3, 0, 9, 2>, false, {}},
+      {"wide 96x128 pd2 dma every 7", run_w<S, 3, VARW_NA3, 0, 9, 7>, false, {}},
+      {"wide 96x128 pd2 tail 10", run_w<S, 3, VARW_NA3, 0, 9, 4, 10>, false, {}},
+      {"wide 96x128 pd1", run_w<S, 3, 0>, false, {}},
+      {"wide 64x128 pd2", run_w<S, 2, VARW_NA3>, false, {}},
+      {"wide 96x128 no-global", run_w<S, 3, VARW_NA3 | VARW_NO_GLOBAL>, false, {}},
+      {"wide 96x128 mfma-only rand", run_w<S, 3, VARW_NA3 | VARW_MFMA_ONLY>, false, {}},
       {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
-      {"mfma-only low-entropy regs", run<S, VAR_MFMA_ONLY>, false, {}},
-      {"mfma-only random regs", run<S, VAR_MFMA_ONLY | VAR_RAND_REGS>, false, {}},
+      {"64x64 mfma-only random regs", run<S, VAR_MFMA_ONLY | VAR_RAND_REGS>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
     for (auto &v : vars) {
       const float ms = v.fn(a, st, e0, e1);
       if (r > 0) v.ms.push_back(ms);
     }
-  { // correctness of the candidate loop against the baseline loop (bitwise on C)
+  { // correctness of the candidate kernels against the plain loop (bitwise on C)
     std::vector<double> c0(M * N), c1(M * N);
     run<S, 0>(a, st, e0, e1);
     CK(hipMemcpy(c0.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
-    CK(hipMemset(C, 0xFF, 8 * M * N));
-    for (int which = 0; which < 3; which++) {
+    for (int which = 0; which < 5; which++) {
       CK(hipMemset(C, 0xFF, 8 * M * N));
-      if (which == 0) run<S, VAR_SHIPPED>(a, st, e0, e1);
-      if (which == 1) run_pp<S, 0>(a, st, e0, e1);
-      if (which == 2) run_throttled<S, VAR_SHIPPED>(a, st, e0, e1);
+      if (which == 0) run_throttled<S, VAR_SHIPPED>(a, st, e0, e1);
+      if (which == 1) run_w<S, 3, VARW_NA3>(a, st, e0, e1);
+      if (which == 2) run_w<S, 3, 0>(a, st, e0, e1);
+      if (which == 3) run_w<S, 3, VARW_NA3, 16>(a, st, e0, e1);
+      if (which == 4) run_w<S, 2, VARW_NA3>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
       for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
       std::printf("check variant %d vs plain loop: %zu mismatching elements of %zu\n", which, bad, M * N);
     }
   }
-  for (int which = 0; which < 2; which++) { // per-phase trace of the ping-pong kernel: first round, mid-kernel
-    unsigned long long *tr;
-    const size_t ntr = 64 * 8 * 16 * 8;
-    CK(hipMalloc(&tr, ntr * 8));
-    CK(hipMemset(tr, 0, ntr * 8));
-    SliceGemmArgs b = a;
-    b.trace = tr;
-    b.trace_block0 = which ? 4096 : 0;
-    run_pp<S, 3>(b, st, e0, e1);
-    std::vector<unsigned long long> h(ntr);
-    CK(hipMemcpy(h.data(), tr, ntr * 8, hipMemcpyDeviceToHost));
-    const char *names[2][7] = {{"45 MFMA", "wait vmcnt", "barrier", "copy issue", "frag reads", "wait lgkm", "barrier"},
-                               {"copy issue", "frag reads", "wait lgkm", "barrier", "45 MFMA", "wait vmcnt", "barrier"}};
-    for (int g = 0; g < 2; g++) {
-      double sum[7] = {0}, tot = 0;
-      int cnt = 0;
-      for (int blk = 0; blk < 64; blk++)
-        for (int w = 4 * g; w < 4 * g + 4; w++)
-          for (int it = 0; it < 15; it++) {
-            const unsigned long long *t = &h[((size_t)(blk * 8 + w) * 16 + it) * 8];
-            const unsigned long long *tn = t + 8;
-            if (!t[0] || !tn[0]) continue;
-            for (int k = 0; k < 6; k++) sum[k] += (double)(t[k + 1] - t[k]);
-            sum[6] += (double)(tn[0] - t[6]);
-            tot += (double)(tn[0] - t[0]);
-            cnt++;
-          }
-      std::printf("pp trace G%d, workgroups %u..: %.0f ticks per k-step (%d samples):", g, b.trace_block0, tot / cnt, cnt);
-      for (int k = 0; k < 7; k++) std::printf("  %s %.0f", names[g][k], sum[k] / cnt);
-      std::printf("\n");
-    }
-    CK(hipFree(tr));
-  }
   const double ops = 45.0 * 2.0 * M * N * K;
-  std::printf("N=%zu S=%d rounds=%d  (TOPS = 45*2*N^3 / t)\n", N, S, rounds);
+  std::printf("M=%zu N=%zu K=%zu S=%d rounds=%d  (TOPS = 45*2*MNK / t)\n", M, N, K, S, rounds);
   for (auto &v : vars) {
     std::sort(v.ms.begin(), v.ms.end());
     const float med = v.ms[v.ms.size() / 2], mn = v.ms.front();
