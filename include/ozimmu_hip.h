@@ -8,20 +8,21 @@
  *    (<rocblas/rocblas.h>, <hipblas/hipblas.h>); anything it does not take over is forwarded to the
  *    next definition found with dlsym(RTLD_NEXT, ...) exactly like src/utils.hpp:117-141:
  *
- *      rocblas_create_handle, rocblas_destroy_handle      <- cublasCreate_v2 / cublasDestroy_v2 (src/cublas.cu:104-131)
- *      rocblas_dgemm, rocblas_dgemm_64                    <- cublasDgemm_v2 (src/cublas.cu:280-295)
- *      rocblas_gemm_ex (all-f64_r case)                   <- cublasGemmEx   (src/cublas.cu:133-278)
- *      rocblas_dgemm_strided_batched                      <- cublasDgemmStridedBatched (src/cublas.cu:474-492)
- *      rocblas_zgemm, rocblas_gemm_ex (all-f64_c case)    <- cublasZgemm_v2 (src/cublas.cu:297-313)
- *      rocblas_zgemm_strided_batched                      <- cublasZgemmStridedBatched (src/cublas.cu:494-512)
- *      rocblas_gemm_strided_batched_ex (f64_r / f64_c)    <- cublasGemmStridedBatchedEx (src/cublas.cu:315-472)
- *      hipblasDgemm, hipblasZgemm, hipblasGemmEx,         <- same, for applications that bind hipBLAS
- *      hipblas{D,Z}gemmStridedBatched,                       directly (hipBLAS itself calls the rocBLAS
- *      hipblasGemmStridedBatchedEx                           entry points above)
+ *      rocblas_create_handle, rocblas_destroy_handle       <- cublasCreate_v2 / cublasDestroy_v2 (src/cublas.cu:104-131)
+ *      rocblas_dgemm[_64]                                  <- cublasDgemm_v2 (src/cublas.cu:280-295)
+ *      rocblas_gemm_ex[_64] (all-f64_r / all-f64_c case)   <- cublasGemmEx   (src/cublas.cu:133-278)
+ *      rocblas_dgemm_strided_batched[_64]                  <- cublasDgemmStridedBatched (src/cublas.cu:474-492)
+ *      rocblas_zgemm[_64]                                  <- cublasZgemm_v2 (src/cublas.cu:297-313)
+ *      rocblas_zgemm_strided_batched[_64]                  <- cublasZgemmStridedBatched (src/cublas.cu:494-512)
+ *      rocblas_gemm_strided_batched_ex[_64]                <- cublasGemmStridedBatchedEx (src/cublas.cu:315-472)
+ *      hipblas{D,Z}gemm[_64], hipblasGemmEx[WithFlags][_64],   <- same, for applications that bind hipBLAS directly
+ *      hipblas{D,Z}gemmStridedBatched[_64],                       (hipBLAS itself calls the rocBLAS entry points
+ *      hipblasGemmStridedBatchedEx[WithFlags][_64]                 above, including the ILP64 `_64` ones)
  *
  *    Environment (src/cublas.cu:18-48, :62-83; src/handle.cu:25-30; src/utils.hpp:88-115; README.md:54-77):
  *      OZIMMU_COMPUTE_MODE = dgemm | sgemm | fp64_int8_3..fp64_int8_18 | fp64_int8_auto  (read per call;
- *                            unset/unknown -> dgemm = pass through; sgemm -> pass through, documented)
+ *                            unset/unknown -> dgemm = pass through; sgemm -> FP32 vendor GEMM on converted copies,
+ *                            ozimmu_hip_gemm_f32)
  *      OZIMMU_INTERCEPT_THRESHOLD_M / _N / _K (default 1024), OZIMMU_AUTO_AVG_MANTISSA_LOSS_THRESHOLD,
  *      OZIMMU_INFO, OZIMMU_ERROR, OZIMMU_MALLOC_ASYNC, OZIMMU_ENABLE_CULIP_PROFILING.
  *
@@ -99,12 +100,38 @@ size_t ozimmu_hip_working_memory_size(ozimmu_operation_t op_A, ozimmu_operation_
                                       ozimmu_compute_mode_t compute_mode);
 
 /* ozimmu.hpp:75-82 (src/gemm.cu:524-653).  0 ok; 1 invalid shape / alignment (src/gemm.cu:554-556);
- * 2 unsupported mode value; 3 HIP failure (the reference would throw).  element_kind OZIMMU_COMPLX: a, b, c are
- * interleaved double-complex, alpha/beta point to {re, im} (gemm_int8<cuDoubleComplex>, src/gemm.cu:412-521). */
+ * 2 unsupported mode value; 3 device / vendor failure with C untouched (the reference would throw); 4 failure after
+ * C had been modified (complex path: beta scaling and the four products update C in place) -- C is undefined and
+ * must not be handed to a fallback GEMM.  element_kind OZIMMU_COMPLX: a, b, c are interleaved double-complex,
+ * alpha/beta point to {re, im} (gemm_int8<cuDoubleComplex>, src/gemm.cu:412-521).
+ * BLAS quick returns and out-of-range sizes run on the vendor GEMM: k == 0, alpha == 0 (C = beta*C, A and B are not
+ * read), k > 2^30 (no exact slice width, src/split.cu:520-536), m or n >= 2^31. */
 int ozimmu_hip_gemm(ozimmu_hip_handle_t handle, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
                     size_t n, size_t k, const void *alpha, const void *a_ptr, size_t lda, const void *b_ptr,
                     size_t ldb, const void *beta, void *c_ptr, size_t ldc,
                     ozimmu_compute_mode_t compute_mode, ozimmu_element_kind_t element_kind);
+
+/* The same with the stream passed along: the handle's stream is switched and the GEMM enqueued under one lock, which
+ * is what the interposer needs when several host threads drive one device on different streams (the reference keeps
+ * one unguarded global handle, src/cublas.cu:58, :149-151). */
+int ozimmu_hip_gemm_on_stream(ozimmu_hip_handle_t handle, void *hip_stream, ozimmu_operation_t op_A,
+                              ozimmu_operation_t op_B, size_t m, size_t n, size_t k, const void *alpha,
+                              const void *a_ptr, size_t lda, const void *b_ptr, size_t ldb, const void *beta,
+                              void *c_ptr, size_t ldc, ozimmu_compute_mode_t compute_mode,
+                              ozimmu_element_kind_t element_kind);
+
+/* cublas{D,Z}gemmStridedBatched / cublasGemmStridedBatchedEx (src/cublas.cu:315-512): matrix i of the batch starts
+ * stride_x * i elements after the first (strides may be 0 for A and B).  The reference loops over the batch
+ * (src/cublas.cu:380-406); here the whole batch goes through one set of launches (batch index = a grid dimension,
+ * batch-strided workspace), per-matrix results identical to ozimmu_hip_gemm.  fp64_int8_auto decides per matrix and
+ * therefore runs the sequential form.  Status as ozimmu_hip_gemm; 4 also when an earlier part of the batch was
+ * already updated. */
+int ozimmu_hip_gemm_strided_batched(ozimmu_hip_handle_t handle, void *hip_stream, ozimmu_operation_t op_A,
+                                    ozimmu_operation_t op_B, size_t m, size_t n, size_t k, const void *alpha,
+                                    const void *a_ptr, size_t lda, long long stride_a, const void *b_ptr, size_t ldb,
+                                    long long stride_b, const void *beta, void *c_ptr, size_t ldc, long long stride_c,
+                                    size_t batch_count, ozimmu_compute_mode_t compute_mode,
+                                    ozimmu_element_kind_t element_kind);
 
 /* ozimmu.hpp:84-94 (src/split.cu:454-518).  Blocks on one 128-byte D2H copy like the reference (:404-408).
  * Returns a fp64_int8_N mode or OZIMMU_DGEMM when no N in 3..18 meets the threshold. */

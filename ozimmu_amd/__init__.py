@@ -70,6 +70,12 @@ def lib():
     L.ozimmu_hip_gemm.restype = i
     L.ozimmu_hip_gemm.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz, i, i]
     L.ozimmu_hip_gemm_f32.restype = i
+    ll = C.c_longlong
+    L.ozimmu_hip_gemm_on_stream.restype = i
+    L.ozimmu_hip_gemm_on_stream.argtypes = [vp, vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz, i, i]
+    L.ozimmu_hip_gemm_strided_batched.restype = i
+    L.ozimmu_hip_gemm_strided_batched.argtypes = [vp, vp, i, i, sz, sz, sz, vp, vp, sz, ll, vp, sz, ll, vp, vp, sz, ll,
+                                                  sz, i, i]
     L.ozimmu_hip_gemm_f32.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz, i]
     L.ozimmu_hip_auto_mode_select.restype = i
     L.ozimmu_hip_auto_mode_select.argtypes = [vp, i, i, sz, sz, sz, vp, sz, vp, sz, i, d]
@@ -203,6 +209,36 @@ def gemm(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr
     return int(lib().ozimmu_hip_gemm(handle.ptr, _op(op_A), _op(op_B), m, n, k, C.addressof(al), _ptr(a_ptr), lda,
                                      _ptr(b_ptr), ldb, C.addressof(be), _ptr(c_ptr), ldc, _mode(compute_mode),
                                      element_kind))
+
+
+def _scalars(alpha, beta, element_kind):
+    if element_kind == complx:
+        return ((C.c_double * 2)(complex(alpha).real, complex(alpha).imag),
+                (C.c_double * 2)(complex(beta).real, complex(beta).imag))
+    return C.c_double(alpha), C.c_double(beta)
+
+
+def _stream_ptr(stream):
+    return C.c_void_p(getattr(stream, "cuda_stream", stream) or None)
+
+
+def gemm_on_stream(handle, stream, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc, compute_mode,
+                   element_kind=real):
+    """gemm with the stream passed along (stream switch and enqueue under one lock); stream: torch stream or raw handle"""
+    al, be = _scalars(alpha, beta, element_kind)
+    return int(lib().ozimmu_hip_gemm_on_stream(handle.ptr, _stream_ptr(stream), _op(op_A), _op(op_B), m, n, k,
+                                               C.addressof(al), _ptr(a_ptr), lda, _ptr(b_ptr), ldb, C.addressof(be),
+                                               _ptr(c_ptr), ldc, _mode(compute_mode), element_kind))
+
+
+def gemm_strided_batched(handle, stream, op_A, op_B, m, n, k, alpha, a_ptr, lda, stride_a, b_ptr, ldb, stride_b, beta,
+                         c_ptr, ldc, stride_c, batch_count, compute_mode, element_kind=real):
+    """cublas{D,Z}gemmStridedBatched semantics (src/cublas.cu:315-512); strides in elements"""
+    al, be = _scalars(alpha, beta, element_kind)
+    return int(lib().ozimmu_hip_gemm_strided_batched(
+        handle.ptr, _stream_ptr(stream), _op(op_A), _op(op_B), m, n, k, C.addressof(al), _ptr(a_ptr), lda, stride_a,
+        _ptr(b_ptr), ldb, stride_b, C.addressof(be), _ptr(c_ptr), ldc, stride_c, batch_count, _mode(compute_mode),
+        element_kind))
 
 
 def gemm_f32(handle, op_A, op_B, m, n, k, alpha, a_ptr, lda, b_ptr, ldb, beta, c_ptr, ldc, element_kind=real):

@@ -130,6 +130,19 @@ static bool hip_ok(hipError_t e, const char *what) {
   return false;
 }
 
+// Test hook (tests/test_gpu_robustness.py): OZIMMU_HIP_TEST_FAIL_LAUNCH=n makes the n-th slice-GEMM launch of a call fail
+// the way a rejected launch does, so that the error paths (C untouched -> vendor fallback; C already modified -> error
+// status, no fallback) can be exercised without breaking the device.
+static bool launch_gemm_checked(int S, const SliceGemmArgs &g, hipStream_t stream, int &launch_index) {
+  launch_index++;
+  if (const char *e = getenv("OZIMMU_HIP_TEST_FAIL_LAUNCH"))
+    if (std::atoi(e) == launch_index) {
+      log_error("HIP failure in slice_gemm: injected by OZIMMU_HIP_TEST_FAIL_LAUNCH");
+      return false;
+    }
+  return hip_ok(launch_slice_gemm(S, g, stream), "slice_gemm");
+}
+
 // src/utils.hpp:143-168
 static int check_gemm_shape(ozimmu_operation_t op, size_t m, size_t n, size_t ld, const char *mat) {
   if ((op == OZIMMU_OP_N ? m : n) > ld) {
@@ -150,9 +163,21 @@ static int check_address_alignment(const void *p, size_t elem, const char *mat) 
 
 // split of one operand into the workspace; stream ordered
 static bool run_split(ozimmu_hip_handle_t h, const OperandView &v, uint32_t *exps, int S, int L,
-                      int8_t *planes, double *max_exp) {
-  return hip_ok(launch_row_max_exp(v, exps, h->stream), "row_max_exp") &&
-         hip_ok(launch_cut(v, exps, S, L, planes, max_exp, h->stream), "cut");
+                      int8_t *planes, double *max_exp, const Batch &batch = Batch()) {
+  return hip_ok(launch_row_max_exp(v, exps, h->stream, batch), "row_max_exp") &&
+         hip_ok(launch_cut(v, exps, S, L, planes, max_exp, h->stream, batch), "cut");
+}
+
+// a strided batch in BLAS terms: matrix i of an operand starts stride * i ELEMENTS after matrix 0
+struct BatchSpec {
+  size_t count = 1;
+  long long stride_a = 0, stride_b = 0, stride_c = 0;
+};
+
+// zero the exponent words (and phase hints) at the head of `count` workspace slots
+static bool zero_slot_heads(ozimmu_hip_handle_t h, void *base, size_t head_bytes, size_t slot_bytes, size_t count) {
+  if (count == 1) return hip_ok(hipMemsetAsync(base, 0, head_bytes, h->stream), "memset");
+  return hip_ok(hipMemset2DAsync(base, slot_bytes, 0, head_bytes, count, h->stream), "memset2d");
 }
 
 // Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
@@ -176,24 +201,34 @@ static bool ensure_workspace(ozimmu_hip_handle_t h, size_t bytes) {
 }
 
 // gemm_int8<double> (src/gemm.cu:344-410), fused MI355X form.  dump != nullptr: test hook.
+// `bs`: the matrices [0, bs.count) of a strided batch run through ONE set of launches (batch index = a grid dimension,
+// one workspace slot per matrix); the caller keeps count * slot within its workspace budget.
 static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
                           size_t n, size_t k, double alpha, const double *a, size_t lda, const double *b,
-                          size_t ldb, double beta, double *c, size_t ldc, int S, int32_t *dump) {
-  const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/gemm.cu:357
+                          size_t ldb, double beta, double *c, size_t ldc, int S, int32_t *dump,
+                          const BatchSpec &bs = BatchSpec()) {
+  const int L = bits_for_k(k); // src/gemm.cu:357
+  if (L == 0) return 3;        // callers route k == 0 / k > 2^30 to the vendor GEMM
   const size_t kc = max_k_per_pass(S, L);
   const bool acc_needed = needs_acc(k, S);
-  if (dump && k > kc) return 2; // whole-K INT32 sums would not be exact
+  if (dump && (k > kc || bs.count != 1)) return 2; // whole-K INT32 sums would not be exact
   Workspace sz = carve(nullptr, m, n, k, S, acc_needed);
+  const size_t slot = sz.total; // 256-byte aligned
   WorkspaceUse use(h);
-  if (!ensure_workspace(h, sz.total)) return 3;
+  if (!ensure_workspace(h, slot * bs.count)) return 3;
   Workspace w = carve(h->working_memory_ptr, m, n, k, S, acc_needed);
+  Batch ba, bb;
+  ba.count = bb.count = (uint32_t)bs.count;
+  ba.in_stride = bs.stride_a;
+  bb.in_stride = bs.stride_b;
+  ba.ws_stride = bb.ws_stride = slot;
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  if (!hip_ok(hipMemsetAsync(w.exps_a, 0, w.exps_bytes, h->stream), "memset")) return 3;
-  if (!run_split(h, view_A(op_A, m, k, a, lda), w.exps_a, S, L, w.planes_a, w.ea)) return 3;
+  if (!zero_slot_heads(h, w.exps_a, w.exps_bytes, slot, bs.count)) return 3;
+  if (!run_split(h, view_A(op_A, m, k, a, lda), w.exps_a, S, L, w.planes_a, w.ea, ba)) return 3;
   if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
-  if (!run_split(h, view_B(op_B, k, n, b, ldb), w.exps_b, S, L, w.planes_b, w.eb)) return 3;
+  if (!run_split(h, view_B(op_B, k, n, b, ldb), w.exps_b, S, L, w.planes_b, w.eb, bb)) return 3;
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
 
   SliceGemmArgs g{};
@@ -212,17 +247,24 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   g.c = c;
   g.ldc = ldc;
   g.acc = w.acc;
-  g.phase = env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) ? nullptr : w.phase;
-  g.throttle = throttle_for(m, n, k);
+  // the phase hint coordinates the workgroups of ONE product: a batch runs without it
+  g.phase = (bs.count > 1 || env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false)) ? nullptr : w.phase;
+  g.throttle = bs.count > 1 ? 0u : throttle_for(m, n, k);
+  g.batch = (uint32_t)bs.count;
+  g.ws_stride = slot;
+  g.c_stride = bs.stride_c;
   g.dump = dump;
   g.dump_only = dump ? 1 : 0;
   const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
+  int launches = 0;
   for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
     g.kb0 = kb0;
     g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
     g.acc_in = kb0 != 0;
     g.final = g.kb1 == g.KB;
-    if (!hip_ok(launch_slice_gemm(S, g, h->stream), "slice_gemm")) return 3;
+    // C is written by the final launch(es) only (earlier passes go to the FP64 workspace); S > 12 splits the final
+    // pass into two launches of which only the second writes C: a failed launch leaves C untouched
+    if (!launch_gemm_checked(S, g, h->stream, launches)) return 3;
   }
   if (prof) {
     if (!hip_ok(hipEventRecord(h->ev[3], h->stream), "event")) return 3;
@@ -281,28 +323,41 @@ static WorkspaceZ carve_z(void *base, size_t m, size_t n, size_t k, int S, bool 
 // as the real path; its epilogue adds the scaled product into the complex C.
 static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
                              size_t n, size_t k, const double *alpha, const double *a, size_t lda, const double *b,
-                             size_t ldb, const double *beta, double *c, size_t ldc, int S) {
-  const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k);
+                             size_t ldb, const double *beta, double *c, size_t ldc, int S,
+                             const BatchSpec &bs = BatchSpec()) {
+  const int L = bits_for_k(k);
+  if (L == 0) return 3;
   const size_t kc = max_k_per_pass(S, L);
   const bool acc_needed = needs_acc(k, S);
   WorkspaceZ sz = carve_z(nullptr, m, n, k, S, acc_needed);
+  const size_t slot = sz.total;
   WorkspaceUse use(h);
-  if (!ensure_workspace(h, sz.total)) return 3;
+  if (!ensure_workspace(h, slot * bs.count)) return 3;
   WorkspaceZ w = carve_z(h->working_memory_ptr, m, n, k, S, acc_needed);
+  Batch ba, bb; // strides of the real views: 2 doubles per complex element
+  ba.count = bb.count = (uint32_t)bs.count;
+  ba.in_stride = 2 * bs.stride_a;
+  bb.in_stride = 2 * bs.stride_b;
+  ba.ws_stride = bb.ws_stride = slot;
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  if (!hip_ok(hipMemsetAsync(w.exps_a[0], 0, w.exps_bytes, h->stream), "memset")) return 3;
+  if (!zero_slot_heads(h, w.exps_a[0], w.exps_bytes, slot, bs.count)) return 3;
   for (int part = 0; part < 2; part++)
-    if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), w.exps_a[part], S, L, w.planes_a[part], w.ea[part]))
+    if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), w.exps_a[part], S, L, w.planes_a[part], w.ea[part], ba))
       return 3;
   if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
   for (int part = 0; part < 2; part++)
-    if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), w.exps_b[part], S, L, w.planes_b[part], w.eb[part]))
+    if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), w.exps_b[part], S, L, w.planes_b[part], w.eb[part], bb))
       return 3;
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
 
-  if (!hip_ok(launch_scale_c_complex(m, n, c, ldc, beta[0], beta[1], h->stream), "scale_c")) return 3; // :477
+  // From here on C is modified in place (beta scaling, then four accumulating products): a failure below is reported
+  // as status 4 so that no caller hands the half-updated C to another GEMM (beta would be applied twice).
+  if (!hip_ok(launch_scale_c_complex(m, n, c, ldc, beta[0], beta[1], h->stream, (uint32_t)bs.count, bs.stride_c),
+              "scale_c"))
+    return 3; // :477
+  int launches = 0;
 
   static const int order[4][2] = {{1, 1}, {0, 0}, {1, 0}, {0, 1}}; // src/gemm.cu:479-480
   for (const auto &pq : order) {
@@ -329,20 +384,23 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     g.c = c;
     g.ldc = ldc;
     g.acc = w.acc;
-    g.phase = env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) ? nullptr : w.phase;
-    g.throttle = throttle_for(m, n, k);
+    g.phase = (bs.count > 1 || env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false)) ? nullptr : w.phase;
+    g.throttle = bs.count > 1 ? 0u : throttle_for(m, n, k);
+    g.batch = (uint32_t)bs.count;
+    g.ws_stride = slot;
+    g.c_stride = bs.stride_c;
     const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
     for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
       g.kb0 = kb0;
       g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
       g.acc_in = kb0 != 0;
       g.final = g.kb1 == g.KB;
-      if (!hip_ok(launch_slice_gemm(S, g, h->stream), "slice_gemm")) return 3;
+      if (!launch_gemm_checked(S, g, h->stream, launches)) return 4;
     }
   }
   if (prof) {
-    if (!hip_ok(hipEventRecord(h->ev[3], h->stream), "event")) return 3;
-    if (!hip_ok(hipEventSynchronize(h->ev[3]), "event sync")) return 3;
+    if (!hip_ok(hipEventRecord(h->ev[3], h->stream), "event")) return 4;
+    if (!hip_ok(hipEventSynchronize(h->ev[3]), "event sync")) return 4;
     for (int i = 0; i < 3; i++) {
       float ms = 0;
       hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]);
@@ -434,7 +492,9 @@ int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
 }
 
 void ozimmu_hip_set_stream(ozimmu_hip_handle_t h, void *hip_stream) { // src/handle.cu:54-61
-  if (h) h->stream = (hipStream_t)hip_stream;
+  if (!h) return;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
+  h->stream = (hipStream_t)hip_stream;
 }
 
 void ozimmu_hip_enable_profiling(ozimmu_hip_handle_t h) {
@@ -481,7 +541,10 @@ double ozimmu_hip_get_auto_mantissa_loss_threashold(ozimmu_hip_handle_t h) {
 }
 
 size_t ozimmu_hip_reallocate_working_memory(ozimmu_hip_handle_t h, size_t size_in_byte) { // src/handle.cu:63-93
-  if (!h || size_in_byte <= h->current_working_memory_size) return 0;
+  if (!h) return 0;
+  // the old block is released here: no other thread may be between carving it and enqueueing its launches
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
+  if (size_in_byte <= h->current_working_memory_size) return 0;
   log_info("Reallocated memory : " + std::to_string(size_in_byte) + " B");
   if (h->working_memory_ptr) {
     // kernels already enqueued on the stream still use the old block: release it in stream order
@@ -509,6 +572,7 @@ size_t ozimmu_hip_working_memory_size(ozimmu_operation_t, ozimmu_operation_t, si
   int S = num_split_of_mode(mode);
   if (mode == OZIMMU_FP64_INT8_AUTO) S = 18; // worst case of what auto may select
   if (S == 0) return 0;
+  if (bits_for_k(k) == 0) return 0; // k == 0 or k > 2^30: no Ozaki path (ozimmu_hip_gemm runs the vendor GEMM)
   if (element_kind != OZIMMU_REAL) return carve_z(nullptr, m, n, k, S, needs_acc(k, S)).total;
   return carve(nullptr, m, n, k, S, needs_acc(k, S)).total;
 }
@@ -530,6 +594,7 @@ int ozimmu_hip_native_dgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozim
   static set_stream_t set_stream = (set_stream_t)vendor_symbol("rocblas_set_stream");
   static dgemm_t dgemm = (dgemm_t)vendor_symbol("rocblas_dgemm");
   if (!create || !set_stream || !dgemm) return (int)rocblas_status_internal_error;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx); // lazy private handle + its stream are per-handle state
   if (!h->rocblas_handle) {
     rocblas_handle rh = nullptr;
     const rocblas_status st = create(&rh);
@@ -556,6 +621,7 @@ static int native_zgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_o
   static set_stream_t set_stream = (set_stream_t)vendor_symbol("rocblas_set_stream");
   static zgemm_t zgemm = (zgemm_t)vendor_symbol("rocblas_zgemm");
   if (!create || !set_stream || !zgemm) return (int)rocblas_status_internal_error;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
   if (!h->rocblas_handle) {
     rocblas_handle rh = nullptr;
     const rocblas_status st = create(&rh);
@@ -710,15 +776,25 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
   arg_error |= check_address_alignment(a, elem, "A");
   arg_error |= check_address_alignment(b, elem, "B");
   arg_error |= check_address_alignment(c, elem, "B"); // sic: the reference labels C as "B" too
-  if (arg_error) return 1;
+  if (arg_error || !alpha || !beta) return 1;
   if ((int)mode < 0 || (int)mode > (int)OZIMMU_FP64_INT8_AUTO) {
     log_error("Not implemented (unknown compute mode)"); // OZIMMU_NOT_IMPLEMENTED throws in the reference
     return 2;
   }
   if (m == 0 || n == 0) return 0;
   const bool cplx = element_kind != OZIMMU_REAL;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx); // the whole enqueue, including auto mode's recursion
 
-  if (mode == OZIMMU_FP64_INT8_AUTO) { // src/gemm.cu:628-638
+  // Calls the Ozaki path does not cover run on the vendor GEMM, which implements the BLAS semantics for them:
+  //   * k == 0 or alpha == 0: C = beta * C without reading A and B (the split would turn a NaN in an unused A into a
+  //     NaN row of C);
+  //   * k > 2^30: no slice width keeps the INT32 products exact (get_bits_per_int8 returns 0, src/split.cu:520-536);
+  //   * m or n >= 2^31: the kernels index rows and columns with 32 bits.
+  const double *al = (const double *)alpha;
+  const bool alpha_zero = al[0] == 0.0 && (!cplx || al[1] == 0.0);
+  const bool vendor_only = k == 0 || alpha_zero || bits_for_k(k) == 0 || m >= ((size_t)1 << 31) || n >= ((size_t)1 << 31);
+
+  if (mode == OZIMMU_FP64_INT8_AUTO && !vendor_only) { // src/gemm.cu:628-638
     const ozimmu_compute_mode_t auto_mode = ozimmu_hip_auto_mode_select(
         h, op_A, op_B, m, n, k, a, lda, b, ldb, element_kind, h->avg_mantissa_loss_threshold);
     log_info(std::string("AUTO selected mode = ") + ozimmu_hip_get_compute_mode_name_str(auto_mode) +
@@ -728,19 +804,91 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
   if (mode == OZIMMU_SGEMM) // src/cublas.cu:169-186 (the reference's library entry throws NOT_IMPLEMENTED here)
     return ozimmu_hip_gemm_f32(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, element_kind);
   const int S = num_split_of_mode(mode);
-  if (S == 0 || (k == 0 && !cplx)) {
-    // `dgemm` (src/gemm.cu:639-645); k == 0 also goes native
+  if (S == 0 || vendor_only) { // `dgemm` (src/gemm.cu:639-645)
     const int st = cplx ? native_zgemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc)
                         : ozimmu_hip_native_dgemm(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a,
                                                   lda, (const double *)b, ldb, (const double *)beta, (double *)c, ldc);
     return st == 0 ? 0 : 3;
   }
-  std::lock_guard<std::recursive_mutex> lock(h->mtx);
   if (cplx)
     return gemm_int8_complex(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)a, lda, (const double *)b,
                              ldb, (const double *)beta, (double *)c, ldc, S);
   return gemm_int8_real(h, op_A, op_B, m, n, k, *(const double *)alpha, (const double *)a, lda,
                         (const double *)b, ldb, *(const double *)beta, (double *)c, ldc, S, nullptr);
+}
+
+int ozimmu_hip_gemm_on_stream(ozimmu_hip_handle_t h, void *hip_stream, ozimmu_operation_t op_A,
+                              ozimmu_operation_t op_B, size_t m, size_t n, size_t k, const void *alpha, const void *a,
+                              size_t lda, const void *b, size_t ldb, const void *beta, void *c, size_t ldc,
+                              ozimmu_compute_mode_t mode, ozimmu_element_kind_t element_kind) {
+  if (!h) return 1;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx); // stream switch + enqueue are one critical section
+  h->stream = (hipStream_t)hip_stream;
+  return ozimmu_hip_gemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, mode, element_kind);
+}
+
+int ozimmu_hip_gemm_strided_batched(ozimmu_hip_handle_t h, void *hip_stream, ozimmu_operation_t op_A,
+                                    ozimmu_operation_t op_B, size_t m, size_t n, size_t k, const void *alpha,
+                                    const void *a, size_t lda, long long stride_a, const void *b, size_t ldb,
+                                    long long stride_b, const void *beta, void *c, size_t ldc, long long stride_c,
+                                    size_t batch_count, ozimmu_compute_mode_t mode, ozimmu_element_kind_t element_kind) {
+  if (!h) return 1;
+  int arg_error = 0; // src/gemm.cu:535-556, once for the whole batch
+  arg_error |= check_gemm_shape(op_A, m, k, lda, "A");
+  arg_error |= check_gemm_shape(op_B, k, n, ldb, "B");
+  arg_error |= check_gemm_shape(OZIMMU_OP_N, m, n, ldc, "C");
+  const size_t es = element_kind == OZIMMU_REAL ? 8 : 16;
+  arg_error |= check_address_alignment(a, es, "A");
+  arg_error |= check_address_alignment(b, es, "B");
+  arg_error |= check_address_alignment(c, es, "B");
+  if (arg_error || !alpha || !beta) return 1;
+  if ((int)mode < 0 || (int)mode > (int)OZIMMU_FP64_INT8_AUTO) {
+    log_error("Not implemented (unknown compute mode)");
+    return 2;
+  }
+  if (batch_count == 0 || m == 0 || n == 0) return 0;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
+  h->stream = (hipStream_t)hip_stream;
+  const bool cplx = element_kind != OZIMMU_REAL;
+  const double *al = (const double *)alpha;
+  const bool alpha_zero = al[0] == 0.0 && (!cplx || al[1] == 0.0);
+  const int S = num_split_of_mode(mode);
+  auto at = [&](const void *p, long long stride, size_t i) {
+    return (const void *)((const char *)p + (long long)i * stride * (long long)es);
+  };
+  // Per-matrix decisions (fp64_int8_auto), the FP32 mode, native modes and the BLAS quick returns take the reference's
+  // sequential form (src/cublas.cu:380-406).  A failure after the first matrix leaves earlier ones updated: status 4.
+  if (S == 0 || batch_count == 1 || k == 0 || alpha_zero || bits_for_k(k) == 0 || m >= ((size_t)1 << 31) ||
+      n >= ((size_t)1 << 31) || env_enabled("OZIMMU_HIP_BATCH_LOOP", false)) {
+    for (size_t i = 0; i < batch_count; i++) {
+      const int st = ozimmu_hip_gemm(h, op_A, op_B, m, n, k, alpha, at(a, stride_a, i), lda, at(b, stride_b, i), ldb, beta,
+                                     (void *)at(c, stride_c, i), ldc, mode, element_kind);
+      if (st) return (i == 0 && st != 4) ? st : 4;
+    }
+    return 0;
+  }
+  // One set of launches per chunk of the batch: as many matrices as fit the workspace budget (default 4 GiB, at
+  // least one) and the grid's y / z range.
+  const size_t slot = cplx ? carve_z(nullptr, m, n, k, S, needs_acc(k, S)).total : carve(nullptr, m, n, k, S, needs_acc(k, S)).total;
+  size_t budget = (size_t)4 << 30;
+  if (const char *e = getenv("OZIMMU_HIP_BATCH_WORKSPACE_BYTES")) budget = std::strtoull(e, nullptr, 10);
+  size_t chunk = std::max<size_t>(1, budget / std::max<size_t>(slot, 1));
+  chunk = std::min<size_t>(chunk, 65535);
+  for (size_t i0 = 0; i0 < batch_count; i0 += chunk) {
+    BatchSpec bs;
+    bs.count = std::min(chunk, batch_count - i0);
+    bs.stride_a = stride_a;
+    bs.stride_b = stride_b;
+    bs.stride_c = stride_c;
+    const int st = cplx ? gemm_int8_complex(h, op_A, op_B, m, n, k, (const double *)alpha, (const double *)at(a, stride_a, i0),
+                                            lda, (const double *)at(b, stride_b, i0), ldb, (const double *)beta,
+                                            (double *)at(c, stride_c, i0), ldc, S, bs)
+                        : gemm_int8_real(h, op_A, op_B, m, n, k, *(const double *)alpha, (const double *)at(a, stride_a, i0),
+                                         lda, (const double *)at(b, stride_b, i0), ldb, *(const double *)beta,
+                                         (double *)at(c, stride_c, i0), ldc, S, nullptr, bs);
+    if (st) return (i0 == 0 && st != 4) ? st : 4;
+  }
+  return 0;
 }
 
 int ozimmu_hip_diagonal_sums(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,

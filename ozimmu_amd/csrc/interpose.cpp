@@ -1,25 +1,33 @@
-// interpose.cpp — the LD_PRELOAD drop-in boundary: rocBLAS / hipBLAS DGEMM entry points.
+// interpose.cpp — the LD_PRELOAD drop-in boundary: rocBLAS / hipBLAS FP64 GEMM entry points.
 //
 // Replaces the reference's cuBLAS hijack layer /root/reference/src/cublas.cu:103-513:
 //   cublasCreate_v2 / cublasDestroy_v2   (:104-131)  -> rocblas_create_handle / rocblas_destroy_handle
-//   cublasGemmEx                         (:133-278)  -> rocblas_gemm_ex, hipblasGemmEx (all-FP64 real case)
-//   cublasDgemm_v2                       (:280-295)  -> rocblas_dgemm, rocblas_dgemm_64, hipblasDgemm
-//   cublasDgemmStridedBatched            (:474-492)  -> rocblas_dgemm_strided_batched, hipblasDgemmStridedBatched (sequential loop, :380-406)
-//   cublasZgemm_v2                       (:297-313)  -> rocblas_zgemm, hipblasZgemm (and the f64_c case of rocblas_gemm_ex)
-//   cublasZgemmStridedBatched            (:494-512)  -> rocblas_zgemm_strided_batched, hipblasZgemmStridedBatched
-//   cublasGemmStridedBatchedEx           (:315-472)  -> rocblas_gemm_strided_batched_ex, hipblasGemmStridedBatchedEx
+//   cublasGemmEx                         (:133-278)  -> rocblas_gemm_ex[_64], hipblasGemmEx[_64], hipblasGemmExWithFlags[_64]
+//   cublasDgemm_v2                       (:280-295)  -> rocblas_dgemm[_64], hipblasDgemm[_64]
+//   cublasZgemm_v2                       (:297-313)  -> rocblas_zgemm[_64], hipblasZgemm[_64] (and the f64_c case of gemm_ex)
+//   cublasGemmStridedBatchedEx           (:315-472)  -> rocblas_gemm_strided_batched_ex[_64], hipblasGemmStridedBatchedEx[_64],
+//                                                       hipblasGemmStridedBatchedExWithFlags[_64]
+//   cublasDgemmStridedBatched            (:474-492)  -> rocblas_dgemm_strided_batched[_64], hipblasDgemmStridedBatched[_64]
+//   cublasZgemmStridedBatched            (:494-512)  -> rocblas_zgemm_strided_batched[_64], hipblasZgemmStridedBatched[_64]
 //   sgemm compute mode                   (:169-186, :355-376) -> ozimmu_hip_gemm_f32 (FP32 vendor GEMM on converted copies)
-// Originals are found with dlsym(RTLD_NEXT) (src/utils.hpp:117-141).
+// Originals are found with dlsym(RTLD_NEXT) (src/utils.hpp:117-141).  The ILP64 (`_64`) twins matter because libhipblas
+// imports the rocBLAS `_64` symbols and HPL-style ILP64 builds call them directly: without them such callers would
+// bypass the shim silently.
 //
 // Documented deviations from the reference (SURVEY.md §8a "quirks"):
 //   * `n` is compared with OZIMMU_INTERCEPT_THRESHOLD_N (the reference compares it with _K, src/cublas.cu:145);
 //   * the global handle is created lazily on first use and never dereferenced when absent (:144);
 //   * one handle PER DEVICE (workspace on the device that runs the GEMM); all are released when the LAST vendor
 //     handle created through this shim is destroyed, not on any destroy (:117-126);
-//   * an internal failure falls back to the vendor routine instead of reporting SUCCESS (:215-219);
-//   * device pointer mode, out-of-place gemm_ex (C != D) and complex types are passed through untouched;
+//   * the strided-batched entry points run the whole batch through ONE set of launches (ozimmu_hip_gemm_strided_batched)
+//     instead of the reference's sequential per-matrix loop (:380-406);
+//   * a failure BEFORE C was touched falls back to the vendor routine; a failure after C was modified is reported as an
+//     error status (the reference overwrites every status with SUCCESS, :215-219) -- never a silent double update;
+//   * device pointer mode, out-of-place gemm_ex (C != D) and conjugate-transposed complex operands are passed through;
 //   * a thread-local guard keeps the shim from re-intercepting calls made underneath itself
-//     (hipBLAS -> rocBLAS, and this library's own native-DGEMM fallback).
+//     (hipBLAS -> rocBLAS, and this library's own native-DGEMM fallback);
+//   * the caller's stream travels WITH the call (ozimmu_hip_gemm_on_stream takes the handle's lock before it switches
+//     streams), so host threads that share a device cannot enqueue on each other's streams.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <hipblas/hipblas.h>
@@ -50,9 +58,9 @@ struct DepthGuard {
   ~DepthGuard() { --t_depth; }
 };
 
-template <class F> F original(const char *name) {
-  return reinterpret_cast<F>(vendor_symbol(name));
-}
+template <class F> F original(const char *name) { return reinterpret_cast<F>(vendor_symbol(name)); }
+// the vendor's definition of the entry point being defined: same prototype, next in the lookup order
+#define OZ_ORIGINAL(name) static const auto fn = original<decltype(&name)>(#name)
 
 // src/cublas.cu:18-48
 ozimmu_compute_mode_t get_compute_mode() { return ozimmu_hip_compute_mode_from_str(getenv("OZIMMU_COMPUTE_MODE")); }
@@ -88,26 +96,44 @@ bool culip_enabled() { // src/culip.cu:41-50
   return v && std::string(v) != "0";
 }
 
-ozimmu_operation_t to_oz(rocblas_operation op) { // src/cublas.cu:50-56: every non-N is T
-  return op == rocblas_operation_none ? OZIMMU_OP_N : OZIMMU_OP_T;
-}
 const char *op_str(ozimmu_operation_t op) { return op == OZIMMU_OP_N ? "N" : "T"; }
 
-// The intercept predicate + the Ozaki path.  true = handled (C holds the result).
-bool try_ozaki(hipStream_t stream, bool host_pointer_mode, ozimmu_operation_t op_a, ozimmu_operation_t op_b,
-               long long m, long long n, long long k, const void *alpha, const void *A, long long lda,
-               const void *B, long long ldb, const void *beta, void *C, long long ldc, bool cplx = false) {
-  if (t_depth > 0) return false;
+// outcome of an attempt to run a call on the Ozaki path
+enum class Try {
+  NotTaken, // predicate rejected it, or the path failed before C was touched: the vendor routine may run
+  Done,     // C holds the result
+  Failed    // the path failed after C had been modified: report an error, never fall back
+};
+
+struct GemmCall { // one (possibly strided-batched) GEMM in BLAS terms; strides in elements of the operand type
+  ozimmu_operation_t op_a, op_b;
+  long long m, n, k;
+  const void *alpha, *A;
+  long long lda, stride_a;
+  const void *B;
+  long long ldb, stride_b;
+  const void *beta;
+  void *C;
+  long long ldc, stride_c;
+  long long batch; // 1 for the non-batched entry points
+  bool cplx;
+  bool strided_batched_entry; // reached through a *StridedBatched* entry point (CULiP tag)
+};
+
+// The intercept predicate + the Ozaki path.
+Try try_ozaki(hipStream_t stream, bool host_pointer_mode, const GemmCall &g) {
+  if (t_depth > 0) return Try::NotTaken;
   const ozimmu_compute_mode_t mode = get_compute_mode();
-  if (mode == OZIMMU_DGEMM) return false;
-  if (!host_pointer_mode || m < 0 || n < 0 || k < 0 || !alpha || !beta) return false;
+  if (mode == OZIMMU_DGEMM) return Try::NotTaken;
+  if (!host_pointer_mode || g.m < 0 || g.n < 0 || g.k < 0 || g.batch < 1 || !g.alpha || !g.beta) return Try::NotTaken;
+  // the kernels index rows / columns with 32 bits and the slice width is defined up to k = 2^30 (src/split.cu:520-536)
+  if (g.m >= (1ll << 31) || g.n >= (1ll << 31) || g.k > (1ll << 30) || g.batch >= (1ll << 31)) return Try::NotTaken;
   ozimmu_hip_handle_t h = get_global_handle();
-  if (!h) return false;
+  if (!h) return Try::NotTaken;
   // src/cublas.cu:143-148 (with the threshold_n fix)
-  if (!((unsigned long long)m >= h->intercept_threshold_m && (unsigned long long)n >= h->intercept_threshold_n &&
-        (unsigned long long)k >= h->intercept_threshold_k))
-    return false;
-  ozimmu_hip_set_stream(h, stream); // src/cublas.cu:149-151
+  if (!((unsigned long long)g.m >= h->intercept_threshold_m && (unsigned long long)g.n >= h->intercept_threshold_n &&
+        (unsigned long long)g.k >= h->intercept_threshold_k))
+    return Try::NotTaken;
 
   const bool prof = culip_enabled();
   timespec t0{}, t1{};
@@ -118,66 +144,120 @@ bool try_ozaki(hipStream_t stream, bool host_pointer_mode, ozimmu_operation_t op
   int err;
   {
     DepthGuard guard; // auto mode may fall back to the vendor DGEMM underneath
-    err = ozimmu_hip_gemm(h, op_a, op_b, (size_t)m, (size_t)n, (size_t)k, alpha, A, (size_t)lda, B, (size_t)ldb,
-                          beta, C, (size_t)ldc, mode, cplx ? OZIMMU_COMPLX : OZIMMU_REAL);
+    const ozimmu_element_kind_t kind = g.cplx ? OZIMMU_COMPLX : OZIMMU_REAL;
+    if (!g.strided_batched_entry)
+      err = ozimmu_hip_gemm_on_stream(h, stream, g.op_a, g.op_b, (size_t)g.m, (size_t)g.n, (size_t)g.k, g.alpha, g.A,
+                                      (size_t)g.lda, g.B, (size_t)g.ldb, g.beta, g.C, (size_t)g.ldc, mode, kind);
+    else
+      err = ozimmu_hip_gemm_strided_batched(h, stream, g.op_a, g.op_b, (size_t)g.m, (size_t)g.n, (size_t)g.k, g.alpha,
+                                            g.A, (size_t)g.lda, g.stride_a, g.B, (size_t)g.ldb, g.stride_b, g.beta, g.C,
+                                            (size_t)g.ldc, g.stride_c, (size_t)g.batch, mode, kind);
   }
   if (prof) {
     hipStreamSynchronize(stream);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     const unsigned long ns =
         ((long)t1.tv_sec - (long)t0.tv_sec) * 1000000000l + ((long)t1.tv_nsec - (long)t0.tv_nsec);
-    // src/cublas.cu:157-162 name format
-    std::printf("[CULiP Result][%s%s-%s%s-m%lld-n%lld-k%lld] %luns\n", cplx ? "Z" : "D",
-                ozimmu_hip_get_compute_mode_name_str(mode),
-                op_str(op_a), op_str(op_b), m, n, k, ns);
+    // name formats of src/cublas.cu:157-162 (gemm) and :342-350 (strided batched: one line per call)
+    if (!g.strided_batched_entry)
+      std::printf("[CULiP Result][%s%s-%s%s-m%lld-n%lld-k%lld] %luns\n", g.cplx ? "Z" : "D",
+                  ozimmu_hip_get_compute_mode_name_str(mode), op_str(g.op_a), op_str(g.op_b), g.m, g.n, g.k, ns);
+    else
+      std::printf("[CULiP Result][%s%s_stridedBatched-%s%s-m%lld-n%lld-k%lld-batch_count%lld] %luns\n",
+                  g.cplx ? "Z" : "D", ozimmu_hip_get_compute_mode_name_str(mode), op_str(g.op_a), op_str(g.op_b), g.m,
+                  g.n, g.k, g.batch, ns);
     std::fflush(stdout);
   }
-  if (err) log_error("Ozaki path failed (status " + std::to_string(err) + "); falling back to the vendor DGEMM");
-  return err == 0;
+  if (err == 0) return Try::Done;
+  if (err == 4) {
+    log_error("Ozaki path failed after C had been modified (status 4): reporting an error to the caller");
+    return Try::Failed;
+  }
+  log_error("Ozaki path failed (status " + std::to_string(err) + "); falling back to the vendor GEMM");
+  return Try::NotTaken;
 }
 
-bool rocblas_ctx(rocblas_handle handle, hipStream_t *stream, bool *host_mode) {
-  typedef rocblas_status (*get_stream_t)(rocblas_handle, hipStream_t *);
-  typedef rocblas_status (*get_pm_t)(rocblas_handle, rocblas_pointer_mode *);
-  static get_stream_t get_stream = original<get_stream_t>("rocblas_get_stream");
-  static get_pm_t get_pm = original<get_pm_t>("rocblas_get_pointer_mode");
-  if (!handle || !get_stream || !get_pm) return false;
-  rocblas_pointer_mode pm = rocblas_pointer_mode_host;
-  if (get_stream(handle, stream) != rocblas_status_success) return false;
-  if (get_pm(handle, &pm) != rocblas_status_success) return false;
-  *host_mode = pm == rocblas_pointer_mode_host;
-  return true;
+// ---- vendor-specific glue ------------------------------------------------------------------------------------------
+struct RB { // rocBLAS
+  typedef rocblas_status status;
+  typedef rocblas_handle handle;
+  typedef rocblas_operation operation;
+  static constexpr status ok = rocblas_status_success, err = rocblas_status_internal_error;
+  static constexpr bool guard_forward = true; // the vendor routine may call other rocBLAS entry points
+  static bool ctx(handle h, hipStream_t *stream, bool *host_mode) {
+    static const auto get_stream = original<decltype(&rocblas_get_stream)>("rocblas_get_stream");
+    static const auto get_pm = original<decltype(&rocblas_get_pointer_mode)>("rocblas_get_pointer_mode");
+    if (!h || !get_stream || !get_pm) return false;
+    rocblas_pointer_mode pm = rocblas_pointer_mode_host;
+    if (get_stream(h, stream) != rocblas_status_success) return false;
+    if (get_pm(h, &pm) != rocblas_status_success) return false;
+    *host_mode = pm == rocblas_pointer_mode_host;
+    return true;
+  }
+  static ozimmu_operation_t to_oz(operation op) { // src/cublas.cu:50-56: every non-N is T
+    return op == rocblas_operation_none ? OZIMMU_OP_N : OZIMMU_OP_T;
+  }
+  static bool conj(operation op) { return op == rocblas_operation_conjugate_transpose; }
+};
+struct HB { // hipBLAS: only reached when an application binds hipBLAS statically or resolves these first
+  typedef hipblasStatus_t status;
+  typedef hipblasHandle_t handle;
+  typedef hipblasOperation_t operation;
+  static constexpr status ok = HIPBLAS_STATUS_SUCCESS, err = HIPBLAS_STATUS_INTERNAL_ERROR;
+  // no DepthGuard on the forward: the vendor hipBLAS routine calls the rocBLAS entry point, the normal intercept point
+  static constexpr bool guard_forward = false;
+  static bool ctx(handle h, hipStream_t *stream, bool *host_mode) {
+    static const auto get_stream = original<decltype(&hipblasGetStream)>("hipblasGetStream");
+    static const auto get_pm = original<decltype(&hipblasGetPointerMode)>("hipblasGetPointerMode");
+    if (!h || !get_stream || !get_pm) return false;
+    hipblasPointerMode_t pm = HIPBLAS_POINTER_MODE_HOST;
+    if (get_stream(h, stream) != HIPBLAS_STATUS_SUCCESS) return false;
+    if (get_pm(h, &pm) != HIPBLAS_STATUS_SUCCESS) return false;
+    *host_mode = pm == HIPBLAS_POINTER_MODE_HOST;
+    return true;
+  }
+  static ozimmu_operation_t to_oz(operation op) { return op == HIPBLAS_OP_N ? OZIMMU_OP_N : OZIMMU_OP_T; }
+  static bool conj(operation op) { return op == HIPBLAS_OP_C; }
+};
+
+// Common body of every interposed GEMM: try the Ozaki path when `eligible` (types / in-place checks of the caller),
+// else (or when it declines) forward to the vendor definition.  Complex operands with a conjugate-transpose are passed
+// through: the reference maps every non-N operation to a plain transpose (src/cublas.cu:50-56), wrong for complex data.
+template <class V, class Forward>
+typename V::status entry(bool eligible, typename V::handle handle, typename V::operation ta, typename V::operation tb,
+                         GemmCall g, bool have_fn, Forward forward) {
+  if (t_depth == 0 && eligible && g.batch > 0 && !(g.cplx && (V::conj(ta) || V::conj(tb))) &&
+      get_compute_mode() != OZIMMU_DGEMM) {
+    hipStream_t stream = nullptr;
+    bool host_mode = false;
+    if (V::ctx(handle, &stream, &host_mode)) {
+      g.op_a = V::to_oz(ta);
+      g.op_b = V::to_oz(tb);
+      const Try t = try_ozaki(stream, host_mode, g);
+      if (t == Try::Done) return V::ok;
+      if (t == Try::Failed) return V::err;
+    }
+  }
+  if (!have_fn) return V::err;
+  if (V::guard_forward) {
+    DepthGuard guard;
+    return forward();
+  }
+  return forward();
 }
 
-bool hipblas_ctx(hipblasHandle_t handle, hipStream_t *stream, bool *host_mode) {
-  typedef hipblasStatus_t (*get_stream_t)(hipblasHandle_t, hipStream_t *);
-  typedef hipblasStatus_t (*get_pm_t)(hipblasHandle_t, hipblasPointerMode_t *);
-  static get_stream_t get_stream = original<get_stream_t>("hipblasGetStream");
-  static get_pm_t get_pm = original<get_pm_t>("hipblasGetPointerMode");
-  if (!handle || !get_stream || !get_pm) return false;
-  hipblasPointerMode_t pm = HIPBLAS_POINTER_MODE_HOST;
-  if (get_stream(handle, stream) != HIPBLAS_STATUS_SUCCESS) return false;
-  if (get_pm(handle, &pm) != HIPBLAS_STATUS_SUCCESS) return false;
-  *host_mode = pm == HIPBLAS_POINTER_MODE_HOST;
-  return true;
-}
-
-ozimmu_operation_t hb_to_oz(hipblasOperation_t op) { return op == HIPBLAS_OP_N ? OZIMMU_OP_N : OZIMMU_OP_T; }
-
-// Strided-batched entry points: a sequential loop over the batch like src/cublas.cu:380-406.  `ozaki(i)` runs
-// matrix i through try_ozaki; if the predicate rejects the first matrix nothing has been touched and the caller
-// forwards the whole batch to the vendor routine (returns -1); if a later matrix fails, the remainder is finished
-// with the vendor's non-batched routine `native(i)`.
-template <class Ozaki, class Native> int run_batch(long long batch_count, Ozaki ozaki, Native native) {
-  long long done = 0;
-  for (; done < batch_count; done++)
-    if (!ozaki(done)) break;
-  if (done == batch_count) return 0;
-  if (done == 0) return -1;
-  DepthGuard guard;
-  for (; done < batch_count; done++)
-    if (const int st = native(done)) return st;
-  return 0;
+GemmCall call(long long m, long long n, long long k, const void *alpha, const void *A, long long lda, const void *B,
+              long long ldb, const void *beta, void *C, long long ldc, bool cplx, long long stride_a = 0,
+              long long stride_b = 0, long long stride_c = 0, long long batch = 1, bool sb_entry = false) {
+  GemmCall g{};
+  g.strided_batched_entry = sb_entry;
+  g.m = m; g.n = n; g.k = k;
+  g.alpha = alpha; g.A = A; g.lda = lda; g.stride_a = stride_a;
+  g.B = B; g.ldb = ldb; g.stride_b = stride_b;
+  g.beta = beta; g.C = C; g.ldc = ldc; g.stride_c = stride_c;
+  g.batch = batch;
+  g.cplx = cplx;
+  return g;
 }
 
 } // namespace
@@ -187,8 +267,7 @@ extern "C" {
 // ---- lifecycle (src/cublas.cu:104-131) -----------------------------------------------------------------
 
 rocblas_status rocblas_create_handle(rocblas_handle *handle) {
-  typedef rocblas_status (*fn_t)(rocblas_handle *);
-  static fn_t fn = original<fn_t>("rocblas_create_handle");
+  OZ_ORIGINAL(rocblas_create_handle);
   if (!fn) return rocblas_status_internal_error;
   const rocblas_status st = fn(handle);
   if (st == rocblas_status_success && t_depth == 0) {
@@ -205,8 +284,7 @@ rocblas_status rocblas_create_handle(rocblas_handle *handle) {
 }
 
 rocblas_status rocblas_destroy_handle(rocblas_handle handle) {
-  typedef rocblas_status (*fn_t)(rocblas_handle);
-  static fn_t fn = original<fn_t>("rocblas_destroy_handle");
+  OZ_ORIGINAL(rocblas_destroy_handle);
   if (!fn) return rocblas_status_internal_error;
   if (t_depth == 0 && g_live_vendor_handles.fetch_sub(1) == 1) {
     std::lock_guard<std::mutex> lock(g_mtx);
@@ -227,421 +305,141 @@ rocblas_status rocblas_destroy_handle(rocblas_handle handle) {
   return fn(handle);
 }
 
-// ---- rocBLAS -------------------------------------------------------------------------------------------
-
-rocblas_status rocblas_dgemm(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB,
-                             rocblas_int m, rocblas_int n, rocblas_int k, const double *alpha, const double *A,
-                             rocblas_int lda, const double *B, rocblas_int ldb, const double *beta, double *C,
-                             rocblas_int ldc) {
-  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                 rocblas_int, const double *, const double *, rocblas_int, const double *,
-                                 rocblas_int, const double *, double *, rocblas_int);
-  static fn_t fn = original<fn_t>("rocblas_dgemm");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  if (t_depth == 0 && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A, lda, B, ldb, beta, C, ldc))
-    return rocblas_status_success;
-  if (!fn) return rocblas_status_internal_error;
-  DepthGuard guard;
-  return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
-}
-
-rocblas_status rocblas_dgemm_64(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB,
-                                int64_t m, int64_t n, int64_t k, const double *alpha, const double *A, int64_t lda,
-                                const double *B, int64_t ldb, const double *beta, double *C, int64_t ldc) {
-  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, int64_t, int64_t, int64_t,
-                                 const double *, const double *, int64_t, const double *, int64_t, const double *,
-                                 double *, int64_t);
-  static fn_t fn = original<fn_t>("rocblas_dgemm_64");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  // the fused kernel indexes rows/columns with 32 bits
-  const bool fits = m < (1ll << 31) && n < (1ll << 31) && k < (1ll << 30);
-  if (t_depth == 0 && fits && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A, lda, B, ldb, beta, C, ldc))
-    return rocblas_status_success;
-  if (!fn) return rocblas_status_internal_error;
-  DepthGuard guard;
-  return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
-}
-
-rocblas_status rocblas_gemm_ex(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB,
-                               rocblas_int m, rocblas_int n, rocblas_int k, const void *alpha, const void *a,
-                               rocblas_datatype a_type, rocblas_int lda, const void *b, rocblas_datatype b_type,
-                               rocblas_int ldb, const void *beta, const void *c, rocblas_datatype c_type,
-                               rocblas_int ldc, void *d, rocblas_datatype d_type, rocblas_int ldd,
-                               rocblas_datatype compute_type, rocblas_gemm_algo algo, int32_t solution_index,
-                               uint32_t flags) {
-  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                 rocblas_int, const void *, const void *, rocblas_datatype, rocblas_int, const void *,
-                                 rocblas_datatype, rocblas_int, const void *, const void *, rocblas_datatype,
-                                 rocblas_int, void *, rocblas_datatype, rocblas_int, rocblas_datatype,
-                                 rocblas_gemm_algo, int32_t, uint32_t);
-  static fn_t fn = original<fn_t>("rocblas_gemm_ex");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  // src/cublas.cu:146-148: all operands FP64 real; in place only (C == D)
-  const bool f64 = a_type == rocblas_datatype_f64_r && b_type == rocblas_datatype_f64_r &&
-                   c_type == rocblas_datatype_f64_r && d_type == rocblas_datatype_f64_r &&
-                   compute_type == rocblas_datatype_f64_r && c == d && ldc == ldd;
-  // ... or all FP64 complex (CUDA_C_64F, src/cublas.cu:147-148), without conjugation
-  const bool c64 = a_type == rocblas_datatype_f64_c && b_type == rocblas_datatype_f64_c &&
-                   c_type == rocblas_datatype_f64_c && d_type == rocblas_datatype_f64_c &&
-                   compute_type == rocblas_datatype_f64_c && c == d && ldc == ldd &&
-                   transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
-  if (t_depth == 0 && (f64 || c64) && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, a, lda, b, ldb, beta, d, ldd, c64))
-    return rocblas_status_success;
-  if (!fn) return rocblas_status_internal_error;
-  DepthGuard guard;
-  return fn(handle, transA, transB, m, n, k, alpha, a, a_type, lda, b, b_type, ldb, beta, c, c_type, ldc, d, d_type,
-            ldd, compute_type, algo, solution_index, flags);
-}
-
-rocblas_status rocblas_dgemm_strided_batched(rocblas_handle handle, rocblas_operation transA,
-                                             rocblas_operation transB, rocblas_int m, rocblas_int n, rocblas_int k,
-                                             const double *alpha, const double *A, rocblas_int lda,
-                                             rocblas_stride stride_a, const double *B, rocblas_int ldb,
-                                             rocblas_stride stride_b, const double *beta, double *C, rocblas_int ldc,
-                                             rocblas_stride stride_c, rocblas_int batch_count) {
-  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                 rocblas_int, const double *, const double *, rocblas_int, rocblas_stride,
-                                 const double *, rocblas_int, rocblas_stride, const double *, double *, rocblas_int,
-                                 rocblas_stride, rocblas_int);
-  static fn_t fn = original<fn_t>("rocblas_dgemm_strided_batched");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  if (t_depth == 0 && batch_count > 0 && get_compute_mode() != OZIMMU_DGEMM &&
-      rocblas_ctx(handle, &stream, &host_mode)) {
-    typedef rocblas_status (*dg_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                   rocblas_int, const double *, const double *, rocblas_int, const double *,
-                                   rocblas_int, const double *, double *, rocblas_int);
-    static dg_t dg = original<dg_t>("rocblas_dgemm");
-    const int st = run_batch(
-        batch_count,
-        [&](long long i) {
-          return try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A + i * stride_a, lda,
-                           B + i * stride_b, ldb, beta, C + i * stride_c, ldc);
-        },
-        [&](long long i) {
-          return dg ? (int)dg(handle, transA, transB, m, n, k, alpha, A + i * stride_a, lda, B + i * stride_b, ldb,
-                              beta, C + i * stride_c, ldc)
-                    : (int)rocblas_status_internal_error;
-        });
-    if (st >= 0) return (rocblas_status)st;
+// ---- {d,z}gemm, 32- and 64-bit index twins ---------------------------------------------------------------------------
+#define OZ_GEMM(V, NAME, OP, INT, T, CPLX)                                                                              \
+  V::status NAME(V::handle handle, OP transA, OP transB, INT m, INT n, INT k, const T *alpha, const T *A, INT lda,      \
+                 const T *B, INT ldb, const T *beta, T *C, INT ldc) {                                                   \
+    OZ_ORIGINAL(NAME);                                                                                                  \
+    return entry<V>(true, handle, transA, transB, call(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, CPLX), fn != nullptr, \
+                    [&] { return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc); });          \
   }
-  if (!fn) return rocblas_status_internal_error;
-  DepthGuard guard;
-  return fn(handle, transA, transB, m, n, k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c,
-            batch_count);
-}
+OZ_GEMM(RB, rocblas_dgemm, rocblas_operation, rocblas_int, double, false)
+OZ_GEMM(RB, rocblas_dgemm_64, rocblas_operation, int64_t, double, false)
+OZ_GEMM(RB, rocblas_zgemm, rocblas_operation, rocblas_int, rocblas_double_complex, true)
+OZ_GEMM(RB, rocblas_zgemm_64, rocblas_operation, int64_t, rocblas_double_complex, true)
+OZ_GEMM(HB, hipblasDgemm, hipblasOperation_t, int, double, false)
+OZ_GEMM(HB, hipblasDgemm_64, hipblasOperation_t, int64_t, double, false)
+OZ_GEMM(HB, hipblasZgemm, hipblasOperation_t, int, hipDoubleComplex, true)
+OZ_GEMM(HB, hipblasZgemm_64, hipblasOperation_t, int64_t, hipDoubleComplex, true)
+#undef OZ_GEMM
 
-// cublasZgemm_v2 (src/cublas.cu:297-313).  Conjugate-transpose is passed through: the reference maps every non-N
-// operation to a plain transpose (src/cublas.cu:50-56), which is wrong for complex data.
-rocblas_status rocblas_zgemm(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB, rocblas_int m,
-                             rocblas_int n, rocblas_int k, const rocblas_double_complex *alpha,
-                             const rocblas_double_complex *A, rocblas_int lda, const rocblas_double_complex *B,
-                             rocblas_int ldb, const rocblas_double_complex *beta, rocblas_double_complex *C,
-                             rocblas_int ldc) {
-  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                 rocblas_int, const rocblas_double_complex *, const rocblas_double_complex *,
-                                 rocblas_int, const rocblas_double_complex *, rocblas_int,
-                                 const rocblas_double_complex *, rocblas_double_complex *, rocblas_int);
-  static fn_t fn = original<fn_t>("rocblas_zgemm");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  const bool no_conj = transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
-  if (t_depth == 0 && no_conj && get_compute_mode() != OZIMMU_DGEMM && rocblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, true))
-    return rocblas_status_success;
-  if (!fn) return rocblas_status_internal_error;
-  DepthGuard guard;
-  return fn(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
-}
-
-// cublasZgemmStridedBatched (src/cublas.cu:494-512)
-rocblas_status rocblas_zgemm_strided_batched(rocblas_handle handle, rocblas_operation transA,
-                                             rocblas_operation transB, rocblas_int m, rocblas_int n, rocblas_int k,
-                                             const rocblas_double_complex *alpha, const rocblas_double_complex *A,
-                                             rocblas_int lda, rocblas_stride stride_a,
-                                             const rocblas_double_complex *B, rocblas_int ldb,
-                                             rocblas_stride stride_b, const rocblas_double_complex *beta,
-                                             rocblas_double_complex *C, rocblas_int ldc, rocblas_stride stride_c,
-                                             rocblas_int batch_count) {
-  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                 rocblas_int, const rocblas_double_complex *, const rocblas_double_complex *,
-                                 rocblas_int, rocblas_stride, const rocblas_double_complex *, rocblas_int,
-                                 rocblas_stride, const rocblas_double_complex *, rocblas_double_complex *, rocblas_int,
-                                 rocblas_stride, rocblas_int);
-  static fn_t fn = original<fn_t>("rocblas_zgemm_strided_batched");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  const bool no_conj = transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
-  if (t_depth == 0 && no_conj && batch_count > 0 && get_compute_mode() != OZIMMU_DGEMM &&
-      rocblas_ctx(handle, &stream, &host_mode)) {
-    typedef rocblas_status (*zg_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                   rocblas_int, const rocblas_double_complex *, const rocblas_double_complex *,
-                                   rocblas_int, const rocblas_double_complex *, rocblas_int,
-                                   const rocblas_double_complex *, rocblas_double_complex *, rocblas_int);
-    static zg_t zg = original<zg_t>("rocblas_zgemm");
-    const int st = run_batch(
-        batch_count,
-        [&](long long i) {
-          return try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, A + i * stride_a, lda,
-                           B + i * stride_b, ldb, beta, C + i * stride_c, ldc, true);
-        },
-        [&](long long i) {
-          return zg ? (int)zg(handle, transA, transB, m, n, k, alpha, A + i * stride_a, lda, B + i * stride_b, ldb,
-                              beta, C + i * stride_c, ldc)
-                    : (int)rocblas_status_internal_error;
-        });
-    if (st >= 0) return (rocblas_status)st;
+// ---- {d,z}gemm_strided_batched ------------------------------------------------------------------------------------------
+#define OZ_GEMM_SB(V, NAME, OP, INT, STRIDE, T, CPLX)                                                                   \
+  V::status NAME(V::handle handle, OP transA, OP transB, INT m, INT n, INT k, const T *alpha, const T *A, INT lda,      \
+                 STRIDE stride_a, const T *B, INT ldb, STRIDE stride_b, const T *beta, T *C, INT ldc, STRIDE stride_c,  \
+                 INT batch_count) {                                                                                     \
+    OZ_ORIGINAL(NAME);                                                                                                  \
+    return entry<V>(true, handle, transA, transB,                                                                       \
+                    call(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, CPLX, stride_a, stride_b, stride_c, batch_count, true), \
+                    fn != nullptr, [&] {                                                                                \
+                      return fn(handle, transA, transB, m, n, k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C,    \
+                                ldc, stride_c, batch_count);                                                            \
+                    });                                                                                                 \
   }
-  if (!fn) return rocblas_status_internal_error;
-  DepthGuard guard;
-  return fn(handle, transA, transB, m, n, k, alpha, A, lda, stride_a, B, ldb, stride_b, beta, C, ldc, stride_c,
-            batch_count);
-}
+OZ_GEMM_SB(RB, rocblas_dgemm_strided_batched, rocblas_operation, rocblas_int, rocblas_stride, double, false)
+OZ_GEMM_SB(RB, rocblas_dgemm_strided_batched_64, rocblas_operation, int64_t, rocblas_stride, double, false)
+OZ_GEMM_SB(RB, rocblas_zgemm_strided_batched, rocblas_operation, rocblas_int, rocblas_stride, rocblas_double_complex, true)
+OZ_GEMM_SB(RB, rocblas_zgemm_strided_batched_64, rocblas_operation, int64_t, rocblas_stride, rocblas_double_complex, true)
+OZ_GEMM_SB(HB, hipblasDgemmStridedBatched, hipblasOperation_t, int, long long, double, false)
+OZ_GEMM_SB(HB, hipblasDgemmStridedBatched_64, hipblasOperation_t, int64_t, long long, double, false)
+OZ_GEMM_SB(HB, hipblasZgemmStridedBatched, hipblasOperation_t, int, long long, hipDoubleComplex, true)
+OZ_GEMM_SB(HB, hipblasZgemmStridedBatched_64, hipblasOperation_t, int64_t, long long, hipDoubleComplex, true)
+#undef OZ_GEMM_SB
 
-// cublasGemmStridedBatchedEx (src/cublas.cu:315-472): all-FP64 real or all-FP64 complex, in place (C == D).
-// The name is parenthesised because rocblas.h also defines a backward-compatibility macro of the same name.
-rocblas_status (rocblas_gemm_strided_batched_ex)(rocblas_handle handle, rocblas_operation transA,
-                                                 rocblas_operation transB, rocblas_int m, rocblas_int n,
-                                                 rocblas_int k, const void *alpha, const void *a,
-                                                 rocblas_datatype a_type, rocblas_int lda, rocblas_stride stride_a,
-                                                 const void *b, rocblas_datatype b_type, rocblas_int ldb,
-                                                 rocblas_stride stride_b, const void *beta, const void *c,
-                                                 rocblas_datatype c_type, rocblas_int ldc, rocblas_stride stride_c,
-                                                 void *d, rocblas_datatype d_type, rocblas_int ldd,
-                                                 rocblas_stride stride_d, rocblas_int batch_count,
-                                                 rocblas_datatype compute_type, rocblas_gemm_algo algo,
-                                                 int32_t solution_index, uint32_t flags) {
-  typedef rocblas_status (*fn_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                 rocblas_int, const void *, const void *, rocblas_datatype, rocblas_int,
-                                 rocblas_stride, const void *, rocblas_datatype, rocblas_int, rocblas_stride,
-                                 const void *, const void *, rocblas_datatype, rocblas_int, rocblas_stride, void *,
-                                 rocblas_datatype, rocblas_int, rocblas_stride, rocblas_int, rocblas_datatype,
-                                 rocblas_gemm_algo, int32_t, uint32_t);
-  static fn_t fn = original<fn_t>("rocblas_gemm_strided_batched_ex");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  const bool in_place = c == d && ldc == ldd && stride_c == stride_d;
-  const bool f64 = a_type == rocblas_datatype_f64_r && b_type == rocblas_datatype_f64_r &&
-                   c_type == rocblas_datatype_f64_r && d_type == rocblas_datatype_f64_r &&
-                   compute_type == rocblas_datatype_f64_r && in_place;
-  const bool c64 = a_type == rocblas_datatype_f64_c && b_type == rocblas_datatype_f64_c &&
-                   c_type == rocblas_datatype_f64_c && d_type == rocblas_datatype_f64_c &&
-                   compute_type == rocblas_datatype_f64_c && in_place &&
-                   transA != rocblas_operation_conjugate_transpose && transB != rocblas_operation_conjugate_transpose;
-  if (t_depth == 0 && (f64 || c64) && batch_count > 0 && get_compute_mode() != OZIMMU_DGEMM &&
-      rocblas_ctx(handle, &stream, &host_mode)) {
-    typedef rocblas_status (*ex_t)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int,
-                                   rocblas_int, const void *, const void *, rocblas_datatype, rocblas_int,
-                                   const void *, rocblas_datatype, rocblas_int, const void *, const void *,
-                                   rocblas_datatype, rocblas_int, void *, rocblas_datatype, rocblas_int,
-                                   rocblas_datatype, rocblas_gemm_algo, int32_t, uint32_t);
-    static ex_t ex = original<ex_t>("rocblas_gemm_ex");
-    const size_t es = c64 ? 16 : 8;
-    const char *ap = (const char *)a, *bp = (const char *)b;
-    char *dp = (char *)d;
-    const int st = run_batch(
-        batch_count,
-        [&](long long i) {
-          return try_ozaki(stream, host_mode, to_oz(transA), to_oz(transB), m, n, k, alpha, ap + i * stride_a * es, lda,
-                           bp + i * stride_b * es, ldb, beta, dp + i * stride_d * es, ldd, c64);
-        },
-        [&](long long i) {
-          return ex ? (int)ex(handle, transA, transB, m, n, k, alpha, ap + i * stride_a * es, a_type, lda,
-                              bp + i * stride_b * es, b_type, ldb, beta, dp + i * stride_d * es, c_type, ldc,
-                              dp + i * stride_d * es, d_type, ldd, compute_type, algo, solution_index, flags)
-                    : (int)rocblas_status_internal_error;
-        });
-    if (st >= 0) return (rocblas_status)st;
+// ---- rocblas_gemm_ex / rocblas_gemm_strided_batched_ex: all-FP64 real or all-FP64 complex, in place (C == D) ------------
+// (src/cublas.cu:146-148 accepts CUDA_R_64F / CUDA_C_64F operands only; cuBLAS has no separate D)
+static bool rb_all(rocblas_datatype t, rocblas_datatype a, rocblas_datatype b, rocblas_datatype c, rocblas_datatype d,
+                   rocblas_datatype compute) {
+  return a == t && b == t && c == t && d == t && compute == t;
+}
+#define OZ_RB_GEMM_EX(NAME, INT)                                                                                        \
+  rocblas_status NAME(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB, INT m, INT n, INT k,   \
+                      const void *alpha, const void *a, rocblas_datatype a_type, INT lda, const void *b,                \
+                      rocblas_datatype b_type, INT ldb, const void *beta, const void *c, rocblas_datatype c_type,       \
+                      INT ldc, void *d, rocblas_datatype d_type, INT ldd, rocblas_datatype compute_type,                \
+                      rocblas_gemm_algo algo, int32_t solution_index, uint32_t flags) {                                 \
+    OZ_ORIGINAL(NAME);                                                                                                  \
+    const bool f64 = rb_all(rocblas_datatype_f64_r, a_type, b_type, c_type, d_type, compute_type);                      \
+    const bool c64 = rb_all(rocblas_datatype_f64_c, a_type, b_type, c_type, d_type, compute_type);                      \
+    return entry<RB>((f64 || c64) && c == d && ldc == ldd, handle, transA, transB,                                      \
+                     call(m, n, k, alpha, a, lda, b, ldb, beta, d, ldd, c64), fn != nullptr, [&] {                      \
+                       return fn(handle, transA, transB, m, n, k, alpha, a, a_type, lda, b, b_type, ldb, beta, c,       \
+                                 c_type, ldc, d, d_type, ldd, compute_type, algo, solution_index, flags);               \
+                     });                                                                                                \
   }
-  if (!fn) return rocblas_status_internal_error;
-  DepthGuard guard;
-  return fn(handle, transA, transB, m, n, k, alpha, a, a_type, lda, stride_a, b, b_type, ldb, stride_b, beta, c,
-            c_type, ldc, stride_c, d, d_type, ldd, stride_d, batch_count, compute_type, algo, solution_index, flags);
-}
+OZ_RB_GEMM_EX(rocblas_gemm_ex, rocblas_int)
+OZ_RB_GEMM_EX(rocblas_gemm_ex_64, int64_t)
+#undef OZ_RB_GEMM_EX
 
-// ---- hipBLAS (only reached when an application binds hipBLAS statically or resolves these first) --------
-
-hipblasStatus_t hipblasDgemm(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m,
-                             int n, int k, const double *alpha, const double *AP, int lda, const double *BP, int ldb,
-                             const double *beta, double *CP, int ldc) {
-  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                  const double *, const double *, int, const double *, int, const double *, double *,
-                                  int);
-  static fn_t fn = original<fn_t>("hipblasDgemm");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  if (t_depth == 0 && get_compute_mode() != OZIMMU_DGEMM && hipblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP, lda, BP, ldb, beta, CP,
-                ldc))
-    return HIPBLAS_STATUS_SUCCESS;
-  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
-  // no DepthGuard: the vendor hipblasDgemm calls rocblas_dgemm, which is the normal intercept point
-  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, BP, ldb, beta, CP, ldc);
-}
-
-hipblasStatus_t hipblasGemmEx(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m,
-                              int n, int k, const void *alpha, const void *A, hipDataType aType, int lda,
-                              const void *B, hipDataType bType, int ldb, const void *beta, void *C, hipDataType cType,
-                              int ldc, hipblasComputeType_t computeType, hipblasGemmAlgo_t algo) {
-  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                  const void *, const void *, hipDataType, int, const void *, hipDataType, int,
-                                  const void *, void *, hipDataType, int, hipblasComputeType_t, hipblasGemmAlgo_t);
-  static fn_t fn = original<fn_t>("hipblasGemmEx");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  const bool f64 = aType == HIP_R_64F && bType == HIP_R_64F && cType == HIP_R_64F && computeType == HIPBLAS_COMPUTE_64F;
-  if (t_depth == 0 && f64 && get_compute_mode() != OZIMMU_DGEMM && hipblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, (const double *)alpha,
-                (const double *)A, lda, (const double *)B, ldb, (const double *)beta, (double *)C, ldc))
-    return HIPBLAS_STATUS_SUCCESS;
-  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
-  return fn(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType,
-            algo);
-}
-
-// The remaining hipBLAS twins.  They never run the Ozaki path themselves twice: when the predicate rejects a call
-// the vendor hipBLAS routine forwards to the rocBLAS entry point above, which is the normal intercept point.
-hipblasStatus_t hipblasZgemm(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m,
-                             int n, int k, const hipDoubleComplex *alpha, const hipDoubleComplex *AP, int lda,
-                             const hipDoubleComplex *BP, int ldb, const hipDoubleComplex *beta, hipDoubleComplex *CP,
-                             int ldc) {
-  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                  const hipDoubleComplex *, const hipDoubleComplex *, int, const hipDoubleComplex *,
-                                  int, const hipDoubleComplex *, hipDoubleComplex *, int);
-  static fn_t fn = original<fn_t>("hipblasZgemm");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  const bool no_conj = transA != HIPBLAS_OP_C && transB != HIPBLAS_OP_C;
-  if (t_depth == 0 && no_conj && get_compute_mode() != OZIMMU_DGEMM && hipblas_ctx(handle, &stream, &host_mode) &&
-      try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP, lda, BP, ldb, beta, CP, ldc,
-                true))
-    return HIPBLAS_STATUS_SUCCESS;
-  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
-  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, BP, ldb, beta, CP, ldc);
-}
-
-hipblasStatus_t hipblasDgemmStridedBatched(hipblasHandle_t handle, hipblasOperation_t transA,
-                                           hipblasOperation_t transB, int m, int n, int k, const double *alpha,
-                                           const double *AP, int lda, long long strideA, const double *BP, int ldb,
-                                           long long strideB, const double *beta, double *CP, int ldc,
-                                           long long strideC, int batchCount) {
-  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                  const double *, const double *, int, long long, const double *, int, long long,
-                                  const double *, double *, int, long long, int);
-  static fn_t fn = original<fn_t>("hipblasDgemmStridedBatched");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  if (t_depth == 0 && batchCount > 0 && get_compute_mode() != OZIMMU_DGEMM &&
-      hipblas_ctx(handle, &stream, &host_mode)) {
-    typedef hipblasStatus_t (*dg_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                    const double *, const double *, int, const double *, int, const double *, double *,
-                                    int);
-    static dg_t dg = original<dg_t>("hipblasDgemm");
-    const int st = run_batch(
-        batchCount,
-        [&](long long i) {
-          return try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP + i * strideA, lda,
-                           BP + i * strideB, ldb, beta, CP + i * strideC, ldc);
-        },
-        [&](long long i) {
-          return dg ? (int)dg(handle, transA, transB, m, n, k, alpha, AP + i * strideA, lda, BP + i * strideB, ldb, beta,
-                              CP + i * strideC, ldc)
-                    : (int)HIPBLAS_STATUS_INTERNAL_ERROR;
-        });
-    if (st >= 0) return (hipblasStatus_t)st;
+// The 32-bit name is parenthesised because rocblas.h also defines a backward-compatibility macro of the same name.
+#define OZ_RB_GEMM_SB_EX(DECL, NAME, INT)                                                                               \
+  rocblas_status DECL(rocblas_handle handle, rocblas_operation transA, rocblas_operation transB, INT m, INT n, INT k,   \
+                      const void *alpha, const void *a, rocblas_datatype a_type, INT lda, rocblas_stride stride_a,      \
+                      const void *b, rocblas_datatype b_type, INT ldb, rocblas_stride stride_b, const void *beta,       \
+                      const void *c, rocblas_datatype c_type, INT ldc, rocblas_stride stride_c, void *d,                \
+                      rocblas_datatype d_type, INT ldd, rocblas_stride stride_d, INT batch_count,                       \
+                      rocblas_datatype compute_type, rocblas_gemm_algo algo, int32_t solution_index, uint32_t flags) {  \
+    static const auto fn = original<decltype(&NAME)>(#NAME);                                                           \
+    const bool f64 = rb_all(rocblas_datatype_f64_r, a_type, b_type, c_type, d_type, compute_type);                      \
+    const bool c64 = rb_all(rocblas_datatype_f64_c, a_type, b_type, c_type, d_type, compute_type);                      \
+    return entry<RB>((f64 || c64) && c == d && ldc == ldd && stride_c == stride_d, handle, transA, transB,              \
+                     call(m, n, k, alpha, a, lda, b, ldb, beta, d, ldd, c64, stride_a, stride_b, stride_d, batch_count, true), \
+                     fn != nullptr, [&] {                                                                               \
+                       return fn(handle, transA, transB, m, n, k, alpha, a, a_type, lda, stride_a, b, b_type, ldb,      \
+                                 stride_b, beta, c, c_type, ldc, stride_c, d, d_type, ldd, stride_d, batch_count,       \
+                                 compute_type, algo, solution_index, flags);                                            \
+                     });                                                                                                \
   }
-  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
-  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, strideA, BP, ldb, strideB, beta, CP, ldc, strideC,
-            batchCount);
-}
+OZ_RB_GEMM_SB_EX((rocblas_gemm_strided_batched_ex), rocblas_gemm_strided_batched_ex, rocblas_int)
+OZ_RB_GEMM_SB_EX(rocblas_gemm_strided_batched_ex_64, rocblas_gemm_strided_batched_ex_64, int64_t)
+#undef OZ_RB_GEMM_SB_EX
 
-hipblasStatus_t hipblasZgemmStridedBatched(hipblasHandle_t handle, hipblasOperation_t transA,
-                                           hipblasOperation_t transB, int m, int n, int k,
-                                           const hipDoubleComplex *alpha, const hipDoubleComplex *AP, int lda,
-                                           long long strideA, const hipDoubleComplex *BP, int ldb, long long strideB,
-                                           const hipDoubleComplex *beta, hipDoubleComplex *CP, int ldc,
-                                           long long strideC, int batchCount) {
-  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                  const hipDoubleComplex *, const hipDoubleComplex *, int, long long,
-                                  const hipDoubleComplex *, int, long long, const hipDoubleComplex *, hipDoubleComplex *,
-                                  int, long long, int);
-  static fn_t fn = original<fn_t>("hipblasZgemmStridedBatched");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  const bool no_conj = transA != HIPBLAS_OP_C && transB != HIPBLAS_OP_C;
-  if (t_depth == 0 && no_conj && batchCount > 0 && get_compute_mode() != OZIMMU_DGEMM &&
-      hipblas_ctx(handle, &stream, &host_mode)) {
-    typedef hipblasStatus_t (*zg_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                    const hipDoubleComplex *, const hipDoubleComplex *, int, const hipDoubleComplex *,
-                                    int, const hipDoubleComplex *, hipDoubleComplex *, int);
-    static zg_t zg = original<zg_t>("hipblasZgemm");
-    const int st = run_batch(
-        batchCount,
-        [&](long long i) {
-          return try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, AP + i * strideA, lda,
-                           BP + i * strideB, ldb, beta, CP + i * strideC, ldc, true);
-        },
-        [&](long long i) {
-          return zg ? (int)zg(handle, transA, transB, m, n, k, alpha, AP + i * strideA, lda, BP + i * strideB, ldb, beta,
-                              CP + i * strideC, ldc)
-                    : (int)HIPBLAS_STATUS_INTERNAL_ERROR;
-        });
-    if (st >= 0) return (hipblasStatus_t)st;
-  }
-  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
-  return fn(handle, transA, transB, m, n, k, alpha, AP, lda, strideA, BP, ldb, strideB, beta, CP, ldc, strideC,
-            batchCount);
+// ---- hipblasGemmEx[WithFlags][_64] / hipblasGemmStridedBatchedEx[WithFlags][_64] -------------------------------------------
+static bool hb_all(hipDataType t, hipDataType a, hipDataType b, hipDataType c, hipblasComputeType_t compute) {
+  return a == t && b == t && c == t && compute == HIPBLAS_COMPUTE_64F;
 }
+#define OZ_HB_GEMM_EX(NAME, INT, FLAGS_PARAM, FLAGS_ARG)                                                                \
+  hipblasStatus_t NAME(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, INT m, INT n,      \
+                       INT k, const void *alpha, const void *A, hipDataType aType, INT lda, const void *B,              \
+                       hipDataType bType, INT ldb, const void *beta, void *C, hipDataType cType, INT ldc,               \
+                       hipblasComputeType_t computeType, hipblasGemmAlgo_t algo FLAGS_PARAM) {                          \
+    OZ_ORIGINAL(NAME);                                                                                                  \
+    const bool f64 = hb_all(HIP_R_64F, aType, bType, cType, computeType);                                               \
+    const bool c64 = hb_all(HIP_C_64F, aType, bType, cType, computeType);                                               \
+    return entry<HB>(f64 || c64, handle, transA, transB, call(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, c64),       \
+                     fn != nullptr, [&] {                                                                               \
+                       return fn(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType,  \
+                                 ldc, computeType, algo FLAGS_ARG);                                                     \
+                     });                                                                                                \
+  }
+#define OZ_COMMA ,
+OZ_HB_GEMM_EX(hipblasGemmEx, int, , )
+OZ_HB_GEMM_EX(hipblasGemmEx_64, int64_t, , )
+OZ_HB_GEMM_EX(hipblasGemmExWithFlags, int, OZ_COMMA hipblasGemmFlags_t flags, OZ_COMMA flags)
+OZ_HB_GEMM_EX(hipblasGemmExWithFlags_64, int64_t, OZ_COMMA hipblasGemmFlags_t flags, OZ_COMMA flags)
+#undef OZ_HB_GEMM_EX
 
-hipblasStatus_t hipblasGemmStridedBatchedEx(hipblasHandle_t handle, hipblasOperation_t transA,
-                                            hipblasOperation_t transB, int m, int n, int k, const void *alpha,
-                                            const void *A, hipDataType aType, int lda, hipblasStride strideA,
-                                            const void *B, hipDataType bType, int ldb, hipblasStride strideB,
-                                            const void *beta, void *C, hipDataType cType, int ldc,
-                                            hipblasStride strideC, int batchCount, hipblasComputeType_t computeType,
-                                            hipblasGemmAlgo_t algo) {
-  typedef hipblasStatus_t (*fn_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                  const void *, const void *, hipDataType, int, hipblasStride, const void *,
-                                  hipDataType, int, hipblasStride, const void *, void *, hipDataType, int,
-                                  hipblasStride, int, hipblasComputeType_t, hipblasGemmAlgo_t);
-  static fn_t fn = original<fn_t>("hipblasGemmStridedBatchedEx");
-  hipStream_t stream = nullptr;
-  bool host_mode = false;
-  const bool f64 = aType == HIP_R_64F && bType == HIP_R_64F && cType == HIP_R_64F && computeType == HIPBLAS_COMPUTE_64F;
-  const bool c64 = aType == HIP_C_64F && bType == HIP_C_64F && cType == HIP_C_64F &&
-                   computeType == HIPBLAS_COMPUTE_64F && transA != HIPBLAS_OP_C && transB != HIPBLAS_OP_C;
-  if (t_depth == 0 && (f64 || c64) && batchCount > 0 && get_compute_mode() != OZIMMU_DGEMM &&
-      hipblas_ctx(handle, &stream, &host_mode)) {
-    typedef hipblasStatus_t (*ex_t)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int,
-                                    const void *, const void *, hipDataType, int, const void *, hipDataType, int,
-                                    const void *, void *, hipDataType, int, hipblasComputeType_t, hipblasGemmAlgo_t);
-    static ex_t ex = original<ex_t>("hipblasGemmEx");
-    const size_t es = c64 ? 16 : 8;
-    const char *ap = (const char *)A, *bp = (const char *)B;
-    char *cp = (char *)C;
-    const int st = run_batch(
-        batchCount,
-        [&](long long i) {
-          return try_ozaki(stream, host_mode, hb_to_oz(transA), hb_to_oz(transB), m, n, k, alpha, ap + i * strideA * es,
-                           lda, bp + i * strideB * es, ldb, beta, cp + i * strideC * es, ldc, c64);
-        },
-        [&](long long i) {
-          return ex ? (int)ex(handle, transA, transB, m, n, k, alpha, ap + i * strideA * es, aType, lda,
-                              bp + i * strideB * es, bType, ldb, beta, cp + i * strideC * es, cType, ldc, computeType,
-                              algo)
-                    : (int)HIPBLAS_STATUS_INTERNAL_ERROR;
-        });
-    if (st >= 0) return (hipblasStatus_t)st;
+#define OZ_HB_GEMM_SB_EX(NAME, INT, FLAGS_PARAM, FLAGS_ARG)                                                             \
+  hipblasStatus_t NAME(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, INT m, INT n,      \
+                       INT k, const void *alpha, const void *A, hipDataType aType, INT lda, hipblasStride strideA,      \
+                       const void *B, hipDataType bType, INT ldb, hipblasStride strideB, const void *beta, void *C,     \
+                       hipDataType cType, INT ldc, hipblasStride strideC, INT batchCount,                               \
+                       hipblasComputeType_t computeType, hipblasGemmAlgo_t algo FLAGS_PARAM) {                          \
+    OZ_ORIGINAL(NAME);                                                                                                  \
+    const bool f64 = hb_all(HIP_R_64F, aType, bType, cType, computeType);                                               \
+    const bool c64 = hb_all(HIP_C_64F, aType, bType, cType, computeType);                                               \
+    return entry<HB>(f64 || c64, handle, transA, transB,                                                                \
+                     call(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, c64, strideA, strideB, strideC, batchCount, true),    \
+                     fn != nullptr, [&] {                                                                               \
+                       return fn(handle, transA, transB, m, n, k, alpha, A, aType, lda, strideA, B, bType, ldb,         \
+                                 strideB, beta, C, cType, ldc, strideC, batchCount, computeType, algo FLAGS_ARG);       \
+                     });                                                                                                \
   }
-  if (!fn) return HIPBLAS_STATUS_INTERNAL_ERROR;
-  return fn(handle, transA, transB, m, n, k, alpha, A, aType, lda, strideA, B, bType, ldb, strideB, beta, C, cType, ldc,
-            strideC, batchCount, computeType, algo);
-}
+OZ_HB_GEMM_SB_EX(hipblasGemmStridedBatchedEx, int, , )
+OZ_HB_GEMM_SB_EX(hipblasGemmStridedBatchedEx_64, int64_t, , )
+OZ_HB_GEMM_SB_EX(hipblasGemmStridedBatchedExWithFlags, int, OZ_COMMA hipblasGemmFlags_t flags, OZ_COMMA flags)
+OZ_HB_GEMM_SB_EX(hipblasGemmStridedBatchedExWithFlags_64, int64_t, OZ_COMMA hipblasGemmFlags_t flags, OZ_COMMA flags)
+#undef OZ_HB_GEMM_SB_EX
+#undef OZ_COMMA
 
 } // extern "C"

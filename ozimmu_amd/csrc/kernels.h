@@ -33,13 +33,26 @@ struct SliceGemmArgs {
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue
   uint32_t rba; // row-blocks held by the A planes (filled in by launch_slice_gemm: rows are padded to TILE_ROWS)
+  // strided batch (grid.y = matrix index b): every workspace pointer above (planes, ea, eb, acc) moves by b * ws_stride
+  // BYTES, c by b * c_stride ELEMENTS (doubles, or double-complex when cplx); batch <= 1: a single product
+  uint32_t batch;
+  size_t ws_stride;
+  long long c_stride;
+};
+
+// a batch of equally shaped operands: matrix b reads its input in_stride doubles after matrix 0 and writes into the
+// workspace slot b * ws_stride bytes after slot 0 (grid.z = b)
+struct Batch {
+  uint32_t count = 1;
+  long long in_stride = 0;
+  size_t ws_stride = 0;
 };
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);
 
 // C(complex, m x n, ldc) *= beta  (beta == 0: C = 0 without reading it); init_c_complex, src/gemm.cu:199-239
 hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, double beta_re, double beta_im,
-                                  hipStream_t stream);
+                                  hipStream_t stream, uint32_t batch = 1, long long c_stride = 0);
 
 // element (r, k) of the operand view lives at in[r * stride_r + k * stride_k] (strides in doubles); the smaller
 // stride is the contiguous axis: 1 for real operands, 2 for the Re or Im part of an interleaved complex operand
@@ -50,11 +63,11 @@ struct OperandView {
 };
 
 // exps[r] = max over k of the biased exponent field (11 bits) of row r; exps must be zeroed first
-hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream);
+hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream, const Batch &batch = Batch());
 
 // slices -> tiled planes (layout.h) and max_exp[r] = 2^(e_max+1) (0 for zero rows, NaN for poisoned rows)
 hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, int8_t *planes,
-                      double *max_exp, hipStream_t stream);
+                      double *max_exp, hipStream_t stream, const Batch &batch = Batch());
 
 // tiled planes -> reference layout [S][rows][ldo] (test hook for ozimmu_hip_split_int8)
 hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int8_t *out, size_t ldo,

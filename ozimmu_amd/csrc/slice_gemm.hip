@@ -76,7 +76,8 @@ static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   static std::atomic<uint64_t> attr_done{0};
   if (hipError_t e = allow_dynamic_lds(slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>, lds, attr_done)) return e;
   const uint32_t nb = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>), dim3(nb), dim3(128 * WM), lds, stream, a);
+  hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>), dim3(nb, a.batch > 1 ? a.batch : 1),
+                     dim3(128 * WM), lds, stream, a);
   return hipGetLastError();
 }
 
@@ -170,7 +171,8 @@ static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipSt
   static std::atomic<uint64_t> attr_done{0};
   if (hipError_t e = allow_dynamic_lds(slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>, lds, attr_done)) return e;
   const uint32_t nb = (a.tiles_m + a.tiles_m2) * a.tiles_n;
-  hipLaunchKernelGGL((slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>), dim3(nb), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>), dim3(nb, a.batch > 1 ? a.batch : 1), dim3(256), lds,
+                     stream, a);
   return hipGetLastError();
 }
 
@@ -180,8 +182,11 @@ template <int S, int D0, int ND, int FORCE_WM = 0>
 static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
   if constexpr (WideCfg<S, D0, ND>::ok) {
     const int ncu = cu_count();
-    const WidePlan pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu);
-    if (prefer_wide(pl, (a.N + 127) / 128, ncu)) return launch_wide<S, D0, ND>(a, pl, stream);
+    // a strided batch fills the chip with all its matrices: plan one matrix on the CUs it gets on average
+    const uint32_t nbatch = a.batch > 1 ? a.batch : 1;
+    const int ncu_eff = (int)(ncu / nbatch) > 0 ? (int)(ncu / nbatch) : 1;
+    const WidePlan pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu_eff);
+    if (prefer_wide(pl, (a.N + 127) / 128, ncu_eff)) return launch_wide<S, D0, ND>(a, pl, stream);
   }
   return launch_one<S, D0, ND, FORCE_WM>(a, stream);
 }
@@ -212,9 +217,11 @@ static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
 
 // init_c_complex_kernel (src/gemm.cu:199-223) without its read-after-write bug (:218-219 uses the updated c.x
 // for c.y): both components are computed from the ORIGINAL c.
-__global__ void scale_c_complex_kernel(size_t m, size_t n, double2 *c, size_t ldc, double br, double bi, int zero) {
+__global__ void scale_c_complex_kernel(size_t m, size_t n, double2 *c, size_t ldc, double br, double bi, int zero,
+                                       long long c_stride) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= m * n) return;
+  c += (long long)blockIdx.y * c_stride; // batch
   double2 *p = c + (tid / m) * ldc + tid % m;
   if (zero) {
     *p = make_double2(0.0, 0.0);
@@ -225,10 +232,11 @@ __global__ void scale_c_complex_kernel(size_t m, size_t n, double2 *c, size_t ld
 }
 
 hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, double beta_re, double beta_im,
-                                  hipStream_t stream) {
-  if (m * n == 0) return hipSuccess;
-  hipLaunchKernelGGL(scale_c_complex_kernel, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, stream, m, n,
-                     reinterpret_cast<double2 *>(c), ldc, beta_re, beta_im, (beta_re == 0.0 && beta_im == 0.0) ? 1 : 0);
+                                  hipStream_t stream, uint32_t batch, long long c_stride) {
+  if (m * n == 0 || batch == 0) return hipSuccess;
+  hipLaunchKernelGGL(scale_c_complex_kernel, dim3((unsigned)((m * n + 255) / 256), batch), dim3(256), 0, stream, m, n,
+                     reinterpret_cast<double2 *>(c), ldc, beta_re, beta_im, (beta_re == 0.0 && beta_im == 0.0) ? 1 : 0,
+                     c_stride);
   return hipGetLastError();
 }
 

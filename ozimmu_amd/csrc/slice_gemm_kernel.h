@@ -52,6 +52,22 @@ constexpr int VAR_RAND_REGS = 16384;  // with VAR_MFMA_ONLY: full-entropy operan
 constexpr int VAR_HOT = 65536;        // wrong results: every copy reads an L2-resident 1 MiB window
 constexpr int VAR_HOT1 = 131072;      // wrong results: every copy of a wave re-reads ONE 1 KiB block (L1 hits)
 
+// the arguments of matrix blockIdx.y of a strided batch (kernels.h): workspace pointers move by ws_stride bytes per
+// matrix, C by c_stride elements
+__device__ __forceinline__ SliceGemmArgs batch_view(SliceGemmArgs p) {
+  const size_t b = blockIdx.y;
+  if (p.batch > 1 && b) {
+    const size_t off = b * p.ws_stride;
+    p.a_planes += off;
+    p.b_planes += off;
+    p.ea = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.ea) + off);
+    p.eb = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p.eb) + off);
+    if (p.acc) p.acc = reinterpret_cast<double *>(reinterpret_cast<char *>(p.acc) + off);
+    p.c += (long long)b * p.c_stride * (p.cplx ? 2 : 1);
+  }
+  return p;
+}
+
 // 2^e as a double, e in the normal range
 __device__ __forceinline__ double pow2d(int e) {
   return __longlong_as_double((long long)(1023 + e) << 52);
@@ -128,7 +144,8 @@ __device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, cons
 // WM = A row-blocks (of 32 rows) per workgroup: 2 -> 4 waves, 64x64 tile, two workgroups per CU;
 //                                            4 -> 8 waves, 128x64 tile (-25 % staged bytes per MFMA)
 template <int S, int D0, int ND, int VAR = 0, int WM = 2>
-__global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemmArgs p) {
+__global__ __launch_bounds__(128 * WM, 2) void slice_gemm_kernel(const SliceGemmArgs p_in) {
+  const SliceGemmArgs p = batch_view(p_in);
   // slices 0..SL-1 of both operands are needed for diagonals d=i+j in [D0, D0+ND)
   constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
   constexpr int STAGE_BYTES = (WM + 2) * SL * FRAG_BYTES;

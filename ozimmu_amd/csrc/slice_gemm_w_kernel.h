@@ -42,16 +42,17 @@ __device__ __forceinline__ void mfma_vgpr(v16i &c, const v4i &b, const v4i &a) {
   asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(c) : "v"(b), "v"(a));
 }
 
-// one 1 KiB fragment block HBM/L2 -> LDS: lane l copies 16 bytes from sbase + voff(l) + IMM to LDS lds_dst + IMM + 16*l.
-// sbase and lds_dst are wave-uniform (SGPRs).  M0 carries the LDS base; it is compiler-reserved, so it is saved and
-// restored inside the statement (guide §5.7); s_nop 0: s_mov m0 -> LDS-DMA needs one wait state.
+// One 1 KiB fragment block HBM/L2 -> LDS: lane l copies 16 bytes from sbase + voff(l) + IMM to LDS lds_a + lds_b + IMM
+// + 16*l.  sbase, lds_a, lds_b are wave-uniform (SGPRs): the loop-invariant part of the source lives in sbase and the
+// k position in the one VGPR voff (lane*16 + k_block * S KiB), so a copy costs one SALU (M0 = LDS base), the mandatory
+// wait state after an M0 write, and the copy itself -- instruction slots between MFMAs are what a lone wave per SIMD
+// is short of.  M0 is compiler-reserved; nothing else in these kernels reads it (tests/test_isa_invariants.py checks
+// the ISA), so it is not saved / restored (-1.8 % kernel time).
 template <int IMM>
-__device__ __forceinline__ void glds16(const int8_t *sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%c4\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM)
+__device__ __forceinline__ void glds16(const int8_t *sbase, uint32_t voff, uint32_t lds_a, uint32_t lds_b) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%c4"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_a), "s"(lds_b), "i"(IMM)
                : "memory");
 }
 
@@ -104,6 +105,9 @@ inline constexpr WSched<S, D0, ND, WA> kWSched{};
 constexpr int VARW_NA3 = 1;        // 3 A buffers (prefetch distance 2); else 2 (distance 1)
 constexpr int VARW_NO_GLOBAL = 2;  // ablation: no staging (LDS holds garbage)
 constexpr int VARW_MFMA_ONLY = 4;  // ablation: no LDS reads either
+constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..107 of the first 32 workgroups -> p.acc
+constexpr int VARW_BAND4 = 16;     // measurement: XCD patch of 4 (M) x 8 (N) tiles instead of 8 x 4
+constexpr int VARW_BAND16 = 32;    // measurement: 16 x 2
 
 // One output tile of (32*WA) x 128: rows start at A row-block rb0, columns at B row-block 4*tn.
 template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0_, int DMAE_, int TAIL_>
@@ -130,8 +134,9 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   const size_t rb_stride = (size_t)p.KB * (size_t)(S * FRAG_BYTES);
   const uint32_t rba_last = p.rba - 1u; // row-blocks the planes hold (rows are padded to 128, tiles to 32*WA)
   const uint32_t lane_off = (uint32_t)lane * 16u;
-  const int8_t *a_src[NQA];
-  uint32_t a_q[NQA];
+  const size_t pass0 = (size_t)p.kb0 * (S * FRAG_BYTES); // first k-block of this pass (k position is relative to it)
+  const int8_t *a_src[NQA]; // loop-invariant source of the wave's t-th A block (SGPR pairs)
+  uint32_t a_lds[NQA];      // its offset inside an A stage
 #pragma unroll
   for (int t = 0; t < NQA; t++) {
     uint32_t q = (uint32_t)(wave * NQA + t);
@@ -139,36 +144,38 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
     const uint32_t a = q / SL, s = q - a * SL;
     uint32_t rb = rb0 + a;
     if (rb > rba_last) rb = rba_last;
-    a_src[t] = p.a_planes + rb * rb_stride + s * FRAG_BYTES;
-    a_q[t] = q;
+    a_src[t] = p.a_planes + rb * rb_stride + s * FRAG_BYTES + pass0;
+    a_lds[t] = q * FRAG_BYTES;
   }
-  const int8_t *b_src = p.b_planes + (size_t)(4u * tn + wave) * rb_stride;
+  const int8_t *b_src = p.b_planes + (size_t)(4u * tn + wave) * rb_stride + pass0;
 
   // The copies are inline asm (glds16): hipcc counts an LDS-DMA builtin on BOTH vmcnt and lgkmcnt, after which every
   // wait it places in front of a fragment's first use is lgkmcnt(0) -- draining the ring read issued just before it
   // (measured in the ISA: 18 x lgkmcnt(0) per k-step instead of counted lgkmcnt(3)).  Invisible to the compiler, the
   // copies are ordered by the explicit counted vmcnt waits below.
   const uint32_t lds0 = (uint32_t)(size_t)((OZ_AS3 char *)smem);
-  auto copy_a = [&](int t, int buf, uint32_t kb) {
+  const uint32_t ldsb0 = lds0 + OFF_B + wave * (SL * FRAG_BYTES);
+  // voff: lane*16 + k-block * S KiB (32 bits: the host keeps a pass below 2^32 bytes per row-block, slice_gemm.hip);
+  // lds_a / lds_b: LDS base of the A / B buffer being filled
+  auto copy_a = [&](int t, uint32_t voff, uint32_t lds_a) {
     if constexpr (NO_GLOBAL) return;
-    glds16<0>(a_src[t] + (size_t)kb * (S * FRAG_BYTES), lane_off, lds0 + buf * A_STAGE + a_q[t] * FRAG_BYTES);
+    glds16<0>(a_src[t], voff, lds_a, a_lds[t]);
   };
-  auto copy_b = [&](auto sc, int buf, uint32_t kb) {
+  auto copy_b = [&](auto sc, uint32_t voff, uint32_t lds_b) {
     if constexpr (NO_GLOBAL) return;
     constexpr int s = decltype(sc)::value;
-    constexpr int G = 3; // immediate-offset groups (the offset also advances the LDS address)
+    constexpr int G = 4; // blocks per immediate-offset group (the offset also advances the LDS address): 0 .. 3072
     constexpr int g0 = s / G * G;
-    const int8_t *gu = b_src + (size_t)kb * (S * FRAG_BYTES) + g0 * FRAG_BYTES;
-    const uint32_t l = lds0 + OFF_B + (buf * 4 + wave) * (SL * FRAG_BYTES) + g0 * FRAG_BYTES;
-    glds16<(s % G) * FRAG_BYTES>(gu, lane_off, l);
+    glds16<(s % G) * FRAG_BYTES>(b_src + g0 * FRAG_BYTES, voff, lds_b, (uint32_t)(g0 * FRAG_BYTES));
   };
   // copy number c (0..NDMA-1) of a stage: A share first (the other waves wait for it), then the private B run
-  auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kb) {
+  auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kstep) {
     constexpr int c = decltype(cc)::value;
+    const uint32_t voff = lane_off + kstep * (uint32_t)(S * FRAG_BYTES);
     if constexpr (c < NQA)
-      copy_a(c, abuf, kb);
+      copy_a(c, voff, lds0 + abuf * A_STAGE);
     else
-      copy_b(std::integral_constant<int, c - NQA>{}, bbuf, kb);
+      copy_b(std::integral_constant<int, c - NQA>{}, voff, ldsb0 + bbuf * B_STAGE);
   };
 
   // ---- accumulators: WA*ND x 16 registers, placed by hand ---------------------------------------------------------
@@ -264,7 +271,7 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
 #pragma unroll
   for (int d = 0; d < PD; d++) {
     if ((uint32_t)d < nk) {
-      static_for<NDMA>([&](auto cc) { copy_n(cc, d % NA, d % 2, p.kb0 + k_issue); });
+      static_for<NDMA>([&](auto cc) { copy_n(cc, d % NA, d % 2, k_issue); });
       k_issue = koff_next(k_issue);
       issued++;
     }
@@ -284,13 +291,24 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   }
   asm volatile("s_nop 7" ::: "memory"); // zero-fill (VALU / v_accvgpr_write) -> first MFMA reading it as C
 
+  uint32_t it = 0;
+  // s_memtime returns through the scalar memory path (lgkmcnt): the stamps of a step are only read after the one
+  // `s_waitcnt lgkmcnt(0)` statement at its end that names them all (guide §5.7 form (ii))
+  auto stamp = [&]() -> unsigned long long {
+    unsigned long long t;
+    asm volatile("s_memtime %0" : "=s"(t));
+    return t;
+  };
   // one k-step.  PF: a stage is prefetched during it; NX: a next stage exists (barrier + refresh at X)
   auto step = [&](auto pf_tag, auto nx_tag) {
     constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value;
+    constexpr bool TRACE = (VARW & VARW_TRACE) != 0;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (TRACE) ts[5] = stamp();
     const int abuf_n = abuf + 1 == NA ? 0 : abuf + 1;                        // next stage
     const int abuf_pf = (PD == 1) ? abuf_n : (abuf_n + 1 == NA ? 0 : abuf_n + 1); // stage PD ahead
     const int bbuf_pf = (PD == 1) ? (bbuf ^ 1) : bbuf;
-    const uint32_t kb_pf = p.kb0 + k_issue;
+    const uint32_t kb_pf = k_issue; // k-step (relative to the pass) of the stage being prefetched
     if constexpr (PF) k_issue = koff_next(k_issue);
     const char *la = la0 + abuf * A_STAGE;
     const char *la_n = la0 + abuf_n * A_STAGE;
@@ -299,20 +317,23 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
       constexpr int s = decltype(sc)::value;
       constexpr int g = SC.sg[s];
       if constexpr (s == XS && NX && !MFMA_ONLY) {
+        if constexpr (TRACE) ts[0] = stamp();
         if constexpr (!NO_GLOBAL) {
           if constexpr (PF && PD > 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NDMA) : "memory");
           else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // own reads of the buffer the barrier releases have returned
+        if constexpr (TRACE) ts[1] = stamp();
+        // NA == 2: the buffer this barrier releases is refilled right behind it, so this wave's reads of it must have
+        // returned.  NA == 3: it is refilled one k-step later; the reads (issued >= 4 MFMAs ago) are long gone by then.
+        if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (TRACE) ts[2] = stamp();
         __builtin_amdgcn_s_barrier(); // A of the next stage visible; nobody reads A of this stage from LDS any more
         asm volatile("" ::: "memory");
+        if constexpr (TRACE) ts[3] = stamp();
         if constexpr (STAG > 0) // de-phase the 4 lockstep waves so that their copies do not queue in the TA
           for (int q = 0; q < wave; q++) asm volatile("s_nop %0" ::"n"(STAG - 1));
-        if (phase && threadIdx.x == 0) __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int j = JT; j < SL; j++) bf[j] = *(const v4i *)(lb_n + j * FRAG_BYTES);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (SC.gfirst[g] == s && !MFMA_ONLY) {
@@ -326,7 +347,9 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
         }
       }
       if constexpr (PF && s >= DMA0 && (s - DMA0) % DMAE == 0 && (s - DMA0) / DMAE < NDMA) {
+        if constexpr (TRACE && s == DMA0 + 4 * DMAE) ts[6] = stamp();
         copy_n(std::integral_constant<int, (s - DMA0) / DMAE>{}, abuf_pf, bbuf_pf, kb_pf);
+        if constexpr (TRACE && s == DMA0 + 4 * DMAE) ts[7] = stamp();
         __builtin_amdgcn_sched_barrier(0);
       }
       constexpr int a = SC.sa[s], i = SC.si[s], j = SC.sj[s];
@@ -334,6 +357,20 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
         mfma(std::integral_constant<int, a * ND + i + j - D0>{}, cf[j], cf[i]);
       else
         mfma(std::integral_constant<int, a * ND + i + j - D0>{}, bf[j], af[g % R]);
+      // behind the barrier the matrix pipe gets its next MFMA first; the refresh of bf[JT..] from the next stage (and
+      // the phase hint) follow in the shadow of the TAIL MFMAs, RPT reads per slot
+      if constexpr (s >= XS && NX && !MFMA_ONLY) {
+        constexpr int RPT = (SL - JT + TAIL - 1) / TAIL;
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+          const int jj = JT + (s - XS) * RPT + q;
+          if (jj < SL) bf[jj] = *(const v4i *)(lb_n + jj * FRAG_BYTES);
+        }
+        if constexpr (s == XS + 1 || (TAIL == 1 && s == XS))
+          if (phase && (it & 3u) == 0 && threadIdx.x == 0)
+            __hip_atomic_store(phase, koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     });
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NX && !MFMA_ONLY) {
@@ -346,11 +383,20 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
       });
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (TRACE) {
+      ts[4] = stamp();
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+s"(ts[0]), "+s"(ts[1]), "+s"(ts[2]), "+s"(ts[3]), "+s"(ts[4]), "+s"(ts[5]), "+s"(ts[6]), "+s"(ts[7]));
+      if (blockIdx.x < 32 && it >= 100 && it < 108 && lane == 0) {
+        uint32_t *tr = reinterpret_cast<uint32_t *>(p.acc) + ((blockIdx.x * 4 + wave) * 8 + (it - 100)) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; q++) tr[q] = (uint32_t)ts[q];
+      }
+    }
     koff = koff_next(koff);
     abuf = abuf_n;
     bbuf ^= 1;
   };
-  uint32_t it = 0;
   for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{});
   for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{});
   for (; it < nk; it++) step(std::false_type{}, std::false_type{});
@@ -370,14 +416,15 @@ __device__ __forceinline__ uint32_t xcd_run_start(uint32_t x, uint32_t n) {
 }
 // logical id inside a region of rows x cols tiles -> (row, col): bands of 8 rows, columns outer inside a band, so
 // that the 32 workgroups an XCD runs concurrently form an 8 (M) x 4 (N) patch that shares A and B panels in its L2
+template <uint32_t BH = 8>
 __device__ __forceinline__ void band_order(uint32_t lid, uint32_t rows, uint32_t cols, uint32_t &r, uint32_t &c) {
-  const uint32_t band_tiles = 8u * cols, nbands = (rows + 7u) >> 3;
+  const uint32_t band_tiles = BH * cols, nbands = (rows + BH - 1u) / BH;
   uint32_t band = lid / band_tiles;
   if (band > nbands - 1) band = nbands - 1;
   const uint32_t rem = lid - band * band_tiles;
-  const uint32_t h = (rows - band * 8u) < 8u ? (rows - band * 8u) : 8u;
+  const uint32_t h = (rows - band * BH) < BH ? (rows - band * BH) : BH;
   c = rem / h;
-  r = band * 8u + rem % h;
+  r = band * BH + rem % h;
 }
 
 // Grid = tiles_m x tiles_n "big" tiles of WA blocks + tiles_m2 x tiles_n "small" tiles of WA-1 blocks below them.  The
@@ -387,18 +434,20 @@ __device__ __forceinline__ void band_order(uint32_t lid, uint32_t rows, uint32_t
 // per-XCD totals equal to what the round-robin dispatch hands each XCD.
 template <int S, int D0, int ND, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL_ = 6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void slice_gemm_w_kernel(
-    const SliceGemmArgs p) {
+    const SliceGemmArgs p_in) {
+  const SliceGemmArgs p = batch_view(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t nbig = p.tiles_m * p.tiles_n, nsmall = p.tiles_m2 * p.tiles_n;
   const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
   const uint32_t nbig_x = (nbig >> 3) + (xcd < (nbig & 7u) ? 1u : 0u);
   uint32_t r, c;
+  constexpr uint32_t BH = (VARW & VARW_BAND4) ? 4u : (VARW & VARW_BAND16) ? 16u : 8u;
   if (idx < nbig_x) {
-    band_order(xcd_run_start(xcd, nbig) + idx, p.tiles_m, p.tiles_n, r, c);
+    band_order<BH>(xcd_run_start(xcd, nbig) + idx, p.tiles_m, p.tiles_n, r, c);
     w_tile<S, D0, ND, WA, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * r, c);
   } else {
     if constexpr (WA > 1) {
-      band_order(xcd_run_start((xcd - (nbig & 7u)) & 7u, nsmall) + (idx - nbig_x), p.tiles_m2, p.tiles_n, r, c);
+      band_order<BH>(xcd_run_start((xcd - (nbig & 7u)) & 7u, nsmall) + (idx - nbig_x), p.tiles_m2, p.tiles_n, r, c);
       w_tile<S, D0, ND, WA - 1, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * p.tiles_m + (WA - 1) * r, c);
     }
   }

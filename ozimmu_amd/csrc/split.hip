@@ -45,7 +45,9 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // k-contiguous operand: element (r,k) at in[r*ld + k].  One wave per row segment, lanes along k.
 __global__ __launch_bounds__(256) void row_max_kcontig_kernel(const double *__restrict__ in, size_t rows,
                                                               size_t K, size_t sr, size_t sk, uint32_t *exps,
-                                                              unsigned kchunk) {
+                                                              unsigned kchunk, long long in_stride, size_t ws_stride) {
+  in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
+  exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(exps) + (size_t)blockIdx.z * ws_stride);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t r = (size_t)blockIdx.x * 4 + wave;
   if (r >= rows) return;
@@ -72,7 +74,9 @@ __global__ __launch_bounds__(256) void row_max_kcontig_kernel(const double *__re
 // row-contiguous operand: element (r,k) at in[k*ld + r].  Lanes along r, the 4 waves interleave k.
 __global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__restrict__ in, size_t rows,
                                                               size_t K, size_t sr, size_t sk, uint32_t *exps,
-                                                              unsigned kchunk) {
+                                                              unsigned kchunk, long long in_stride, size_t ws_stride) {
+  in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
+  exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(exps) + (size_t)blockIdx.z * ws_stride);
   __shared__ unsigned red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t r = (size_t)blockIdx.x * 64 + lane;
@@ -104,18 +108,18 @@ __global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__re
   }
 }
 
-hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream) {
-  if (v.rows == 0 || v.K == 0) return hipSuccess;
+hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream, const Batch &b) {
+  if (v.rows == 0 || v.K == 0 || b.count == 0) return hipSuccess;
   if (v.stride_k < v.stride_r) {
     const unsigned kchunk = 8192;
-    dim3 grid((unsigned)((v.rows + 3) / 4), (unsigned)((v.K + kchunk - 1) / kchunk));
+    dim3 grid((unsigned)((v.rows + 3) / 4), (unsigned)((v.K + kchunk - 1) / kchunk), b.count);
     hipLaunchKernelGGL(row_max_kcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, v.stride_k, exps, kchunk);
+                       v.stride_r, v.stride_k, exps, kchunk, b.in_stride, b.ws_stride);
   } else {
     const unsigned kchunk = 512;
-    dim3 grid((unsigned)((v.rows + 63) / 64), (unsigned)((v.K + kchunk - 1) / kchunk));
+    dim3 grid((unsigned)((v.rows + 63) / 64), (unsigned)((v.K + kchunk - 1) / kchunk), b.count);
     hipLaunchKernelGGL(row_max_rcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, v.stride_k, exps, kchunk);
+                       v.stride_r, v.stride_k, exps, kchunk, b.in_stride, b.ws_stride);
   }
   return hipGetLastError();
 }
@@ -181,8 +185,13 @@ template <bool KCONTIG, bool PREFETCH = KCONTIG>
 __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in, size_t rows, size_t K,
                                                   size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
                                                   int8_t *__restrict__ planes, double *__restrict__ max_exp,
-                                                  size_t RB, size_t KB, int strip) {
+                                                  size_t RB, size_t KB, int strip, long long in_stride,
+                                                  size_t ws_stride) {
   __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
+  in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
+  exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(exps) + (size_t)blockIdx.z * ws_stride);
+  planes += (size_t)blockIdx.z * ws_stride;
+  max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(max_exp) + (size_t)blockIdx.z * ws_stride);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int CUT_STRIP = PREFETCH ? strip : 1;
   // strips along the contiguous axis: k-contiguous -> CUT_STRIP k-blocks of one row-block, else CUT_STRIP row-blocks
@@ -285,20 +294,20 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
 }
 
 hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, int8_t *planes,
-                      double *max_exp, hipStream_t stream) {
+                      double *max_exp, hipStream_t stream, const Batch &b) {
   const size_t RB = row_blocks_padded(v.rows), KB = k_blocks(v.K);
-  if (RB * KB == 0) return hipSuccess;
+  if (RB * KB == 0 || b.count == 0) return hipSuccess;
   const bool kcontig = v.stride_k < v.stride_r;
   // strip length: up to 4 blocks per wave as long as >= 2048 workgroups remain to fill the chip
   const int strip = !kcontig ? 1 : (RB * KB >= 4 * 8192 ? 4 : (RB * KB >= 2 * 8192 ? 2 : 1));
   const size_t strips = ((kcontig ? KB : RB) + strip - 1) / strip * (kcontig ? RB : KB);
-  const unsigned grid = (unsigned)((strips + 3) / 4);
+  const dim3 grid((unsigned)((strips + 3) / 4), 1, b.count);
   if (kcontig)
-    hipLaunchKernelGGL(cut_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip);
+    hipLaunchKernelGGL(cut_kernel<true>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
   else
-    hipLaunchKernelGGL(cut_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip);
+    hipLaunchKernelGGL(cut_kernel<false>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
   return hipGetLastError();
 }
 

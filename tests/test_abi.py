@@ -14,10 +14,12 @@ from oracle import oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ozimmu_hip.h")
 
-INTERPOSED = ["rocblas_create_handle", "rocblas_destroy_handle", "rocblas_dgemm", "rocblas_dgemm_64",
-              "rocblas_gemm_ex", "rocblas_dgemm_strided_batched", "rocblas_zgemm", "rocblas_zgemm_strided_batched",
-              "rocblas_gemm_strided_batched_ex", "hipblasDgemm", "hipblasGemmEx", "hipblasZgemm",
-              "hipblasDgemmStridedBatched", "hipblasZgemmStridedBatched", "hipblasGemmStridedBatchedEx"]
+_FAMILIES = ["rocblas_dgemm", "rocblas_zgemm", "rocblas_gemm_ex", "rocblas_dgemm_strided_batched",
+             "rocblas_zgemm_strided_batched", "rocblas_gemm_strided_batched_ex", "hipblasDgemm", "hipblasZgemm",
+             "hipblasGemmEx", "hipblasGemmExWithFlags", "hipblasDgemmStridedBatched", "hipblasZgemmStridedBatched",
+             "hipblasGemmStridedBatchedEx", "hipblasGemmStridedBatchedExWithFlags"]
+# every FP64 GEMM entry point the vendor libraries export, 32-bit and ILP64 (`_64`) index twins
+INTERPOSED = ["rocblas_create_handle", "rocblas_destroy_handle"] + _FAMILIES + [f + "_64" for f in _FAMILIES]
 
 
 @pytest.fixture(scope="module")
@@ -53,6 +55,23 @@ def test_exports_are_unmangled_c_symbols():
     exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
     for name in declared_functions() + INTERPOSED:
         assert name in exported
+
+
+def test_interposed_surface_covers_the_vendor_fp64_gemm_exports():
+    """every {d,z}gemm / gemm_ex (plain, strided-batched, _64, WithFlags) symbol that the installed rocBLAS / hipBLAS
+    export is defined by the shim: a caller of any of them reaches the intercept predicate"""
+    import glob
+    for lib_glob, pat in (("/opt/rocm/lib/librocblas.so.*", r" T (rocblas_(?:d|z)?gemm(?:_strided_batched)?(?:_ex)?(?:_64)?)$"),
+                          ("/opt/rocm/lib/libhipblas.so.*", r" T (hipblas(?:D|Z)?[Gg]emm(?:StridedBatched)?(?:Ex)?(?:WithFlags)?(?:_64)?)$")):
+        libs = sorted(glob.glob(lib_glob))
+        if not libs:
+            pytest.skip("vendor library not installed")
+        out = subprocess.check_output(["nm", "-D", "--defined-only", libs[0]], text=True)
+        names = set(re.findall(pat, out, flags=re.M))
+        names = {n for n in names if not re.match(r"(rocblas_gemm|hipblasGemm)$", n)}
+        assert names, lib_glob
+        missing = sorted(names - set(INTERPOSED))
+        assert not missing, missing
 
 
 def test_no_link_time_dependency_on_vendor_blas():

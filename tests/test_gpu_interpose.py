@@ -92,6 +92,30 @@ int main(int argc, char** argv) {
   hipStreamSynchronize(st);
   hipMemcpy(C.data(), dC + (size_t)1 * m * n, C.size() * 8, hipMemcpyDeviceToHost);
   printf("RESIDUAL strided_batched_ex %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  // 5. the ILP64 twins: rocblas_dgemm_64, and rocblas_zgemm_64 on (A + 0i)(B + 0i)
+  hipMemcpy(dC, C0.data(), C.size() * 8, hipMemcpyHostToDevice);
+  if (rocblas_dgemm_64(h, oa, ob, m, n, k, &alpha, dA, lda, dB, ldb, &beta, dC, m) != rocblas_status_success) return 7;
+  hipStreamSynchronize(st);
+  hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
+  printf("RESIDUAL dgemm_64 %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  {
+    std::vector<rocblas_double_complex> zA(A.size()), zB(B.size()), zC(C0.size());
+    for (size_t i = 0; i < A.size(); i++) zA[i] = rocblas_double_complex(A[i], 0.0);
+    for (size_t i = 0; i < B.size(); i++) zB[i] = rocblas_double_complex(B[i], 0.0);
+    for (size_t i = 0; i < C0.size(); i++) zC[i] = rocblas_double_complex(C0[i], 0.0);
+    rocblas_double_complex *dzA, *dzB, *dzC;
+    hipMalloc(&dzA, zA.size() * 16); hipMalloc(&dzB, zB.size() * 16); hipMalloc(&dzC, zC.size() * 16);
+    hipMemcpy(dzA, zA.data(), zA.size() * 16, hipMemcpyHostToDevice);
+    hipMemcpy(dzB, zB.data(), zB.size() * 16, hipMemcpyHostToDevice);
+    hipMemcpy(dzC, zC.data(), zC.size() * 16, hipMemcpyHostToDevice);
+    const rocblas_double_complex za(alpha, 0.0), zb(beta, 0.0);
+    if (rocblas_zgemm_64(h, oa, ob, m, n, k, &za, dzA, lda, dzB, ldb, &zb, dzC, m) != rocblas_status_success) return 8;
+    hipStreamSynchronize(st);
+    hipMemcpy(zC.data(), dzC, zC.size() * 16, hipMemcpyDeviceToHost);
+    double imag = 0;
+    for (size_t i = 0; i < zC.size(); i++) { C[i] = std::real(zC[i]); imag = fmax(imag, fabs(std::imag(zC[i]))); }
+    printf("RESIDUAL zgemm_64 %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb) + imag);
+  }
   rocblas_destroy_handle(h);
   return 0;
 }
@@ -125,12 +149,14 @@ def test_preloaded_rocblas_dgemm_runs_the_ozaki_path(driver, ta, tb):
     assert all(v < 1e-14 for v in native.values())
     oz, out = run(driver, [512, ta, tb], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_9",
                   OZIMMU_INFO=1, OZIMMU_ENABLE_CULIP_PROFILING=1, **thr)
-    assert set(oz) == {"dgemm", "gemm_ex", "strided_batched", "strided_batched_ex"}
+    assert set(oz) == {"dgemm", "gemm_ex", "strided_batched", "strided_batched_ex", "dgemm_64", "zgemm_64"}
     assert all(v < 1e-15 for v in oz.values()), oz           # the reference's gate, through the preload
     assert "[ozIMMU LOG] Reallocated memory" in out           # src/handle.cu:69
     # CULiP line format of src/cublas.cu:157-162 / src/culip.cu:19-39
     ops = ("T" if ta else "N") + ("T" if tb else "N")
     assert f"[CULiP Result][Dfp64_int8_9-{ops}-m512-n576-k544]" in out
+    assert f"[CULiP Result][Zfp64_int8_9-{ops}-m512-n576-k544]" in out          # rocblas_zgemm_64
+    assert f"[CULiP Result][Dfp64_int8_9_stridedBatched-{ops}-m512-n576-k544-batch_count3]" in out
     # fewer slices -> visibly larger error: proves the environment knob reaches the kernel
     coarse, _ = run(driver, [512, ta, tb], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_4", **thr)
     assert all(1e-10 < v < 1e-6 for v in coarse.values()), coarse
@@ -213,4 +239,7 @@ def test_pytorch_batched_matmul_is_intercepted():
     assert diffs["fp64_int8_3"][0] > 1e-6 and diffs["fp64_int8_3"][1] > 1e-6, diffs["fp64_int8_3"][:2]
     assert diffs["fp64_int8_10"][0] < 1e-11 and diffs["fp64_int8_10"][1] < 1e-11, diffs["fp64_int8_10"][:2]
     out = diffs["fp64_int8_10"][2]
-    assert out.count("[CULiP Result][Dfp64_int8_10-") == 3 and out.count("[CULiP Result][Zfp64_int8_10-") == 3, out
+    # one line per strided-batched call, in the reference's format (src/cublas.cu:342-350)
+    assert out.count("[CULiP Result][Dfp64_int8_10_stridedBatched-") == 1, out
+    assert out.count("[CULiP Result][Zfp64_int8_10_stridedBatched-") == 1, out
+    assert "-m1100-n1050-k1024-batch_count3]" in out or "-m1050-n1100-k1024-batch_count3]" in out, out

@@ -1,0 +1,307 @@
+"""GPU tests of the host pipeline's robustness: strided batches through one set of
+launches, host threads sharing a handle on different streams, the error paths (failure before / after C was modified),
+BLAS quick returns, the stage profiler's report, and BASELINE config C1 verbatim."""
+import ctypes
+import os
+import subprocess
+import sys
+import textwrap
+import threading
+
+import numpy as np
+import pytest
+
+import ozimmu_amd
+from oracle import oracle as O
+from tests.util import ColMajor, operand, uniform_pm1
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------- strided batches (src/cublas.cu:315-512)
+
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T")])
+@pytest.mark.parametrize("m,n,k,S,batch", [(70, 50, 90, 9, 3), (130, 200, 64, 6, 5), (64, 64, 40, 13, 2)])
+def test_strided_batched_equals_per_matrix_gemm(oz, op_a, op_b, m, n, k, S, batch):
+    """one set of launches for the whole batch == the reference's per-matrix loop, bit for bit, and == the oracle"""
+    import torch
+    m_, h = oz
+    rng = np.random.default_rng(m + n + k + S)
+    ar, ac = (m, k) if op_a == "N" else (k, m)
+    br, bc = (k, n) if op_b == "N" else (n, k)
+    lda, ldb, ldc = ar + 1, br + 2, m + 3
+    sa, sb, sc = lda * ac + 5, ldb * bc + 7, ldc * n + 11          # padded strides
+    A = rng.uniform(-1, 1, batch * sa)
+    B = rng.uniform(-1, 1, batch * sb)
+    C0 = rng.uniform(-1, 1, batch * sc)
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    dC = torch.from_numpy(C0.copy()).cuda()
+    st = m_.gemm_strided_batched(h, torch.cuda.current_stream(), op_a, op_b, m, n, k, 1.25, dA, lda, sa, dB, ldb, sb, -0.5,
+                                 dC, ldc, sc, batch, f"fp64_int8_{S}")
+    _sync()
+    assert st == 0
+    got = dC.cpu().numpy()
+    for i in range(batch):
+        a = np.lib.stride_tricks.as_strided(A[i * sa:], shape=(ar, ac), strides=(8, 8 * lda))
+        b = np.lib.stride_tricks.as_strided(B[i * sb:], shape=(br, bc), strides=(8, 8 * ldb))
+        c_ref = C0[i * sc:i * sc + ldc * n].copy()
+        cv = np.lib.stride_tricks.as_strided(c_ref, shape=(m, n), strides=(8, 8 * ldc))
+        assert O.gemm(op_a, op_b, m, n, k, 1.25, a, b, -0.5, cv, S, O.ORDER_DIAGONAL) == 0
+        np.testing.assert_array_equal(got[i * sc:i * sc + ldc * n].view(np.uint64), c_ref.view(np.uint64))
+    # the gaps between the matrices of C are untouched
+    for i in range(batch - 1):
+        np.testing.assert_array_equal(got[i * sc + ldc * n:(i + 1) * sc], C0[i * sc + ldc * n:(i + 1) * sc])
+
+
+def test_strided_batched_chunks_and_broadcast_operands(oz, monkeypatch):
+    """a workspace budget of one slot forces one chunk per matrix; stride 0 broadcasts A"""
+    import torch
+    m_, h = oz
+    m, n, k, S, batch = 96, 64, 128, 9, 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.rand(k, m, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    b = torch.rand(batch, n, k, dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    out = {}
+    for budget in ("1", str(1 << 34)):
+        monkeypatch.setenv("OZIMMU_HIP_BATCH_WORKSPACE_BYTES", budget)
+        c = torch.zeros(batch, n, m, dtype=torch.float64, device="cuda")
+        assert m_.gemm_strided_batched(h, torch.cuda.current_stream(), "N", "N", m, n, k, 1.0, a, m, 0, b, k, n * k, 0.0, c,
+                                       m, n * m, batch, f"fp64_int8_{S}") == 0
+        _sync()
+        out[budget] = c
+    assert torch.equal(out["1"].view(torch.int64), out[str(1 << 34)].view(torch.int64))
+    ref = torch.matmul(b, a)          # row-major view of the column-major products
+    assert ((out["1"] - ref).norm() / ref.norm()).item() < 1e-15
+
+
+def test_zgemm_strided_batched_equals_per_matrix(oz):
+    import torch
+    m_, h = oz
+    m, n, k, batch = 70, 66, 100, 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.view_as_complex(torch.rand(batch, k, m, 2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
+    b = torch.view_as_complex(torch.rand(batch, n, k, 2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
+    c0 = torch.view_as_complex(torch.rand(batch, n, m, 2, dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
+    cb = c0.clone()
+    assert m_.gemm_strided_batched(h, torch.cuda.current_stream(), "N", "N", m, n, k, 0.5 - 1j, a, m, k * m, b, k, n * k,
+                                   0.25 + 2j, cb, m, n * m, batch, "fp64_int8_9", m_.complx) == 0
+    cl = c0.clone()
+    for i in range(batch):
+        assert m_.gemm(h, "N", "N", m, n, k, 0.5 - 1j, a[i], m, b[i], k, 0.25 + 2j, cl[i], m, "fp64_int8_9", m_.complx) == 0
+    _sync()
+    assert torch.equal(torch.view_as_real(cb).view(torch.int64), torch.view_as_real(cl).view(torch.int64))
+
+
+# ---------------------------------------------------------------- host threads on one handle
+
+def test_two_host_threads_two_streams_share_one_handle(oz):
+    """Each thread enqueues GEMMs with ozimmu_hip_gemm_on_stream on its own stream, reading inputs produced on that
+    stream right before the call and consuming C right after it.  Were a GEMM enqueued on the other thread's stream
+    (the set_stream race of round 1) it would not be ordered with its producer / consumer.  Results must equal the
+    single-threaded run bit for bit."""
+    import torch
+    m_, h = oz
+    n, S, reps = 512, 6, 12
+    base = [torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(4)]
+    _sync()
+
+    def work(tid, stream, out):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(stream):
+            for r in range(reps):
+                a = base[2 * tid] * (1.0 + r)          # produced on this stream
+                b = base[2 * tid + 1] + float(r)
+                c = torch.empty(n, n, dtype=torch.float64, device="cuda")
+                st = m_.gemm_on_stream(h, stream, "N", "T", n, n, n, 1.0, a, n, b, n, 0.0, c, n, f"fp64_int8_{S}")
+                assert st == 0
+                out.append(c.sum(dim=0))               # consumed on this stream
+        stream.synchronize()
+
+    solo = [[], []]
+    for tid in range(2):
+        work(tid, torch.cuda.Stream(), solo[tid])
+    _sync()
+    par = [[], []]
+    threads = [threading.Thread(target=work, args=(tid, torch.cuda.Stream(), par[tid])) for tid in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    _sync()
+    for tid in range(2):
+        for x, y in zip(solo[tid], par[tid]):
+            assert torch.equal(x.view(torch.int64), y.view(torch.int64))
+
+
+# ---------------------------------------------------------------- error paths
+
+def test_injected_launch_failure_real_leaves_c_untouched(oz, monkeypatch):
+    """status 3 = failed before C was written: the caller (the interposer) may fall back to the vendor GEMM"""
+    import torch
+    m_, h = oz
+    n = 128
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda")
+    c = torch.full((n, n), 7.0, dtype=torch.float64, device="cuda")
+    monkeypatch.setenv("OZIMMU_HIP_TEST_FAIL_LAUNCH", "1")
+    monkeypatch.setenv("OZIMMU_ERROR", "0")
+    assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_9") == 3
+    monkeypatch.setenv("OZIMMU_HIP_TEST_FAIL_LAUNCH", "2")           # second launch of the two diagonal passes
+    assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_14") == 3
+    _sync()
+    assert (c == 7.0).all()
+    monkeypatch.delenv("OZIMMU_HIP_TEST_FAIL_LAUNCH")
+    assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_9") == 0
+
+
+def test_injected_launch_failure_complex_reports_modified_c(oz, monkeypatch):
+    """the complex path scales C by beta before its four products: a later failure is status 4, never 3"""
+    import torch
+    m_, h = oz
+    n = 96
+    a = torch.view_as_complex(torch.rand(n, n, 2, dtype=torch.float64, device="cuda"))
+    c = torch.view_as_complex(torch.rand(n, n, 2, dtype=torch.float64, device="cuda"))
+    monkeypatch.setenv("OZIMMU_ERROR", "0")
+    monkeypatch.setenv("OZIMMU_HIP_TEST_FAIL_LAUNCH", "3")
+    assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5 + 0.5j, c, n, "fp64_int8_9", m_.complx) == 4
+
+
+PRELOAD_FAIL = r"""
+#include <hip/hip_runtime_api.h>
+#include <rocblas/rocblas.h>
+#include <cstdio>
+#include <vector>
+int main() {
+  const int n = 256;
+  std::vector<double> A(n * n, 0.5), C(n * n, 2.0), out(n * n);
+  std::vector<rocblas_double_complex> ZA(n * n, rocblas_double_complex(0.5, 0.25)), ZC(n * n, rocblas_double_complex(2.0, 1.0)), zout(n * n);
+  double *dA, *dC; rocblas_double_complex *zA, *zC;
+  hipMalloc(&dA, n * n * 8); hipMalloc(&dC, n * n * 8); hipMalloc(&zA, n * n * 16); hipMalloc(&zC, n * n * 16);
+  hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice); hipMemcpy(dC, C.data(), n * n * 8, hipMemcpyHostToDevice);
+  hipMemcpy(zA, ZA.data(), n * n * 16, hipMemcpyHostToDevice); hipMemcpy(zC, ZC.data(), n * n * 16, hipMemcpyHostToDevice);
+  rocblas_handle h; rocblas_create_handle(&h);
+  const double alpha = 1.0, beta = 0.5;
+  rocblas_status st = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, n, n, n, &alpha, dA, n, dA, n, &beta, dC, n);
+  hipDeviceSynchronize();
+  hipMemcpy(out.data(), dC, n * n * 8, hipMemcpyDeviceToHost);
+  printf("DGEMM status=%d c00=%.6f\n", (int)st, out[0]);          // 0.25*256 + 0.5*2 = 65
+  const rocblas_double_complex za(1.0, 0.0), zb(0.5, 0.0);
+  st = rocblas_zgemm(h, rocblas_operation_none, rocblas_operation_none, n, n, n, &za, zA, n, zA, n, &zb, zC, n);
+  hipDeviceSynchronize();
+  printf("ZGEMM status=%d\n", (int)st);
+  rocblas_destroy_handle(h);
+  return 0;
+}
+"""
+
+
+def test_preload_fallback_only_when_c_is_untouched(tmp_path):
+    """through LD_PRELOAD: a real-path failure (C untouched) falls back to the vendor DGEMM with the right result;
+    a complex-path failure after the beta scaling returns an error status instead of a double-scaled C"""
+    src = tmp_path / "d.cpp"
+    src.write_text(PRELOAD_FAIL)
+    exe = tmp_path / "d"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(src), "-o",
+                           str(exe), "-L/opt/rocm/lib", "-lrocblas", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
+    e.update(LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_9", OZIMMU_INTERCEPT_THRESHOLD_M="64",
+             OZIMMU_INTERCEPT_THRESHOLD_N="64", OZIMMU_INTERCEPT_THRESHOLD_K="64")
+    e1 = dict(e, OZIMMU_HIP_TEST_FAIL_LAUNCH="1")
+    p = subprocess.run([str(exe)], env=e1, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "DGEMM status=0 c00=65.000000" in p.stdout, p.stdout           # vendor fallback, beta applied once
+    assert "falling back to the vendor GEMM" in p.stdout
+    assert "ZGEMM status=0" not in p.stdout and "ZGEMM status=" in p.stdout  # launch 1 of 4 fails after the scaling
+    assert "after C had been modified" in p.stdout
+    p = subprocess.run([str(exe)], env=e, capture_output=True, text=True, timeout=300)
+    assert "DGEMM status=0 c00=65.000000" in p.stdout and "ZGEMM status=0" in p.stdout, p.stdout
+
+
+# ---------------------------------------------------------------- BLAS quick returns / out-of-range sizes
+
+def test_quick_returns_do_not_split_the_operands(oz):
+    """alpha == 0 or k == 0: C = beta*C on the vendor path; A and B are not read (a NaN in A must not reach C)"""
+    import torch
+    m_, h = oz
+    n = 64
+    a = torch.full((n, n), float("nan"), dtype=torch.float64, device="cuda")
+    c = torch.full((n, n), 3.0, dtype=torch.float64, device="cuda")
+    assert m_.gemm(h, "N", "N", n, n, n, 0.0, a, n, a, n, 2.0, c, n, "fp64_int8_9") == 0
+    _sync()
+    assert (c == 6.0).all()
+    assert m_.gemm(h, "N", "N", n, n, 0, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_9") == 0
+    _sync()
+    assert (c == 3.0).all()
+    z = torch.view_as_complex(torch.full((n, n, 2), 1.0, dtype=torch.float64, device="cuda"))
+    za = torch.view_as_complex(torch.full((n, n, 2), float("nan"), dtype=torch.float64, device="cuda"))
+    assert m_.gemm(h, "N", "N", n, n, 0, 1.0, za, n, za, n, 2.0, z, n, "fp64_int8_9", m_.complx) == 0   # was SIGFPE
+    _sync()
+    assert (torch.view_as_real(z) == 2.0).all()
+
+
+def test_working_memory_size_of_degenerate_k():
+    lib = ozimmu_amd.lib()
+    f = lib.ozimmu_hip_working_memory_size
+    assert f(0, 0, 1024, 1024, 0, ozimmu_amd.real, ozimmu_amd.fp64_int8_9) == 0          # was SIGFPE (division by q*q = 0)
+    assert f(0, 0, 1024, 1024, 0, ozimmu_amd.complx, ozimmu_amd.fp64_int8_9) == 0
+    assert f(0, 0, 8, 8, (1 << 30) + 1, ozimmu_amd.real, ozimmu_amd.fp64_int8_9) == 0
+
+
+# ---------------------------------------------------------------- stage profiler (F3: src/handle.cu:246-265)
+
+def test_profiler_report_labels_calls_and_shares(oz, capfd):
+    import torch
+    m_, h = oz
+    n = 512
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda")
+    c = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    m_.clear_profiler_result(h)
+    m_.enable_profiling(h)
+    for _ in range(3):
+        assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.0, c, n, "fp64_int8_9") == 0
+    m_.disable_profiling(h)
+    assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.0, c, n, "fp64_int8_9") == 0     # not counted
+    _sync()
+    capfd.readouterr()
+    m_.print_profiler_result(h, "unit", csv=True)
+    out = capfd.readouterr().out
+    rows = [l.split(",") for l in out.strip().splitlines()]
+    assert rows[0] == ["tag", "label", "calls", "total_ms", "share"]
+    labels = [r[1] for r in rows[1:]]
+    assert labels == ["split_A", "split_B", "int8tc", "accumulate_in_f64", "copy_result"]   # src/gemm.cu:38-48, :393-407
+    assert all(r[0] == "unit" and r[2] == "3" for r in rows[1:])
+    t = {r[1]: float(r[3]) for r in rows[1:]}
+    sh = {r[1]: float(r[4]) for r in rows[1:]}
+    assert t["split_A"] > 0 and t["split_B"] > 0 and t["int8tc"] > 0
+    assert t["accumulate_in_f64"] == 0 and t["copy_result"] == 0      # fused into the int8tc kernel
+    assert abs(sum(sh.values()) - 1.0) < 1e-3
+    m_.print_profiler_result(h, "unit")
+    txt = capfd.readouterr().out
+    assert "[unit] (3 calls)" in txt and all(l in txt for l in labels)
+    m_.clear_profiler_result(h)
+    m_.print_profiler_result(h, "cleared", csv=True)
+    out = capfd.readouterr().out
+    assert all(l.split(",")[2] == "0" and float(l.split(",")[3]) == 0 for l in out.strip().splitlines()[1:])
+
+
+# ---------------------------------------------------------------- BASELINE config C1 verbatim
+
+def test_baseline_config_c1_fp64_int8_6_512_cubed(oz):
+    """C1: fp64_int8_6, M=N=K=512, U[-1,1): HIP result bit-exact vs the oracle (the CPU leg is tests/test_oracle.py)"""
+    m_, h = oz
+    m = n = k = 512
+    rng = np.random.default_rng(0)
+    a = operand("N", m, k, rng, fill=uniform_pm1)
+    b = operand("N", k, n, rng, fill=uniform_pm1)
+    c, c_ref = ColMajor(m, n), ColMajor(m, n)
+    assert m_.gemm(h, "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, "fp64_int8_6") == 0
+    _sync()
+    assert O.gemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, 6, O.ORDER_DIAGONAL) == 0
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+    r = O.relative_residual_sampled("N", "N", m, n, k, a.view, b.view, c.view, ns=2048)
+    assert 1e-12 < r < 1e-10         # six 7-bit slices: the accuracy level of BASELINE.md's curve at S=6

@@ -1,7 +1,8 @@
 """CPU tests of the LD_PRELOAD boundary (ozimmu_amd/csrc/interpose.cpp) without a GPU.
 
 A stub `librocblas.so.5` that records calls stands in for the vendor library; a small C driver linked against
-it calls rocblas_dgemm / rocblas_gemm_ex / rocblas_{d,z}gemm_strided_batched / rocblas_gemm_strided_batched_ex under LD_PRELOAD=libozimmu_hip.so.
+it calls rocblas_dgemm / rocblas_gemm_ex / rocblas_{d,z}gemm_strided_batched / rocblas_gemm_strided_batched_ex and their
+ILP64 `_64` twins under LD_PRELOAD=libozimmu_hip.so.
 Checked: the shim's definitions win symbol resolution, the pass-through reaches the vendor routine with the
 arguments untouched, and the intercept predicate (src/cublas.cu:142-148: mode, thresholds, types) decides as
 documented.  With an Ozaki mode selected and sizes above the thresholds the shim tries its own path, finds
@@ -62,6 +63,48 @@ int rocblas_zgemm_strided_batched(rocblas_handle h, int ta, int tb, int m, int n
   printf("STUB zgemm_strided_batched m=%d n=%d k=%d strides=%lld,%lld,%lld batch=%d\n", m, n, k, sa, sb, sc, batch);
   return 0;
 }
+int rocblas_zgemm_64(rocblas_handle h, int ta, int tb, int64_t m, int64_t n, int64_t k, const void* al, const void* A,
+                     int64_t lda, const void* B, int64_t ldb, const void* be, void* C, int64_t ldc) {
+  (void)h; (void)A; (void)B; (void)C; (void)al; (void)be; (void)lda; (void)ldb; (void)ldc; (void)ta; (void)tb;
+  printf("STUB zgemm_64 m=%lld n=%lld k=%lld\n", (long long)m, (long long)n, (long long)k);
+  return 0;
+}
+int rocblas_gemm_ex_64(rocblas_handle h, int ta, int tb, int64_t m, int64_t n, int64_t k, const void* al, const void* a,
+                       int at, int64_t lda, const void* b, int bt, int64_t ldb, const void* be, const void* c, int ct,
+                       int64_t ldc, void* d, int dt, int64_t ldd, int compute, int algo, int32_t sol, uint32_t flags) {
+  (void)h; (void)al; (void)a; (void)b; (void)be; (void)c; (void)d; (void)lda; (void)ldb; (void)ldc; (void)ldd;
+  (void)algo; (void)sol; (void)flags; (void)ta; (void)tb;
+  printf("STUB gemm_ex_64 m=%lld n=%lld k=%lld types=%d,%d,%d,%d compute=%d\n", (long long)m, (long long)n, (long long)k,
+         at, bt, ct, dt, compute);
+  return 0;
+}
+int rocblas_dgemm_strided_batched_64(rocblas_handle h, int ta, int tb, int64_t m, int64_t n, int64_t k, const double* al,
+                                     const double* A, int64_t lda, long long sa, const double* B, int64_t ldb,
+                                     long long sb, const double* be, double* C, int64_t ldc, long long sc, int64_t batch) {
+  (void)h; (void)A; (void)B; (void)C; (void)al; (void)be; (void)lda; (void)ldb; (void)ldc; (void)ta; (void)tb;
+  printf("STUB dgemm_strided_batched_64 m=%lld n=%lld k=%lld strides=%lld,%lld,%lld batch=%lld\n", (long long)m,
+         (long long)n, (long long)k, sa, sb, sc, (long long)batch);
+  return 0;
+}
+int rocblas_zgemm_strided_batched_64(rocblas_handle h, int ta, int tb, int64_t m, int64_t n, int64_t k, const void* al,
+                                     const void* A, int64_t lda, long long sa, const void* B, int64_t ldb, long long sb,
+                                     const void* be, void* C, int64_t ldc, long long sc, int64_t batch) {
+  (void)h; (void)A; (void)B; (void)C; (void)al; (void)be; (void)lda; (void)ldb; (void)ldc; (void)ta; (void)tb;
+  printf("STUB zgemm_strided_batched_64 m=%lld n=%lld k=%lld strides=%lld,%lld,%lld batch=%lld\n", (long long)m,
+         (long long)n, (long long)k, sa, sb, sc, (long long)batch);
+  return 0;
+}
+int rocblas_gemm_strided_batched_ex_64(rocblas_handle h, int ta, int tb, int64_t m, int64_t n, int64_t k, const void* al,
+                                       const void* a, int at, int64_t lda, long long sa, const void* b, int bt,
+                                       int64_t ldb, long long sb, const void* be, const void* c, int ct, int64_t ldc,
+                                       long long sc, void* d, int dt, int64_t ldd, long long sd, int64_t batch,
+                                       int compute, int algo, int32_t sol, uint32_t flags) {
+  (void)h; (void)al; (void)a; (void)b; (void)be; (void)c; (void)d; (void)lda; (void)ldb; (void)ldc; (void)ldd;
+  (void)algo; (void)sol; (void)flags; (void)ta; (void)tb;
+  printf("STUB gemm_strided_batched_ex_64 m=%lld n=%lld k=%lld types=%d,%d,%d,%d strides=%lld,%lld,%lld,%lld batch=%lld "
+         "compute=%d\n", (long long)m, (long long)n, (long long)k, at, bt, ct, dt, sa, sb, sc, sd, (long long)batch, compute);
+  return 0;
+}
 int rocblas_gemm_strided_batched_ex(rocblas_handle h, int ta, int tb, int m, int n, int k, const void* al, const void* a,
                                     int at, int lda, long long sa, const void* b, int bt, int ldb, long long sb,
                                     const void* be, const void* c, int ct, int ldc, long long sc, void* d, int dt, int ldd,
@@ -95,6 +138,21 @@ int rocblas_zgemm_strided_batched(rocblas_handle, int, int, int, int, int, const
 int rocblas_gemm_strided_batched_ex(rocblas_handle, int, int, int, int, int, const void*, const void*, int, int, long long,
                                     const void*, int, int, long long, const void*, const void*, int, int, long long, void*,
                                     int, int, long long, int, int, int, int32_t, uint32_t);
+int rocblas_zgemm_64(rocblas_handle, int, int, int64_t, int64_t, int64_t, const void*, const void*, int64_t, const void*,
+                     int64_t, const void*, void*, int64_t);
+int rocblas_gemm_ex_64(rocblas_handle, int, int, int64_t, int64_t, int64_t, const void*, const void*, int, int64_t,
+                       const void*, int, int64_t, const void*, const void*, int, int64_t, void*, int, int64_t, int, int,
+                       int32_t, uint32_t);
+int rocblas_dgemm_strided_batched_64(rocblas_handle, int, int, int64_t, int64_t, int64_t, const double*, const double*,
+                                     int64_t, long long, const double*, int64_t, long long, const double*, double*,
+                                     int64_t, long long, int64_t);
+int rocblas_zgemm_strided_batched_64(rocblas_handle, int, int, int64_t, int64_t, int64_t, const void*, const void*,
+                                     int64_t, long long, const void*, int64_t, long long, const void*, void*, int64_t,
+                                     long long, int64_t);
+int rocblas_gemm_strided_batched_ex_64(rocblas_handle, int, int, int64_t, int64_t, int64_t, const void*, const void*, int,
+                                       int64_t, long long, const void*, int, int64_t, long long, const void*, const void*,
+                                       int, int64_t, long long, void*, int, int64_t, long long, int64_t, int, int,
+                                       int32_t, uint32_t);
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 64;
   int device_mode = argc > 2 ? atoi(argv[2]) : 0;
@@ -120,6 +178,21 @@ int main(int argc, char** argv) {
   st = rocblas_gemm_strided_batched_ex(h, 111, 111, n, n, n, &alpha, fake, 152, n, n * n, fake, 152, n, n * n, &beta, fake,
                                        152, n, n * n, fake, 152, n, n * n, 4, 152, 0, 0, 0);
   printf("APP strided_ex status=%d\n", st);
+  /* the ILP64 twins (libhipblas and ILP64 applications bind these) */
+  st = rocblas_zgemm_64(h, 111, 111, n, n, n, zalpha, fake, n, fake, n, zbeta, fake, n);
+  printf("APP zgemm_64 status=%d\n", st);
+  st = rocblas_gemm_ex_64(h, 111, 111, n, n, n, &alpha, fake, 152, n, fake, 152, n, &beta, fake, 152, n, fake, 152, n, 152,
+                          0, 0, 0);
+  printf("APP gemm_ex_64 status=%d\n", st);
+  st = rocblas_dgemm_strided_batched_64(h, 111, 111, n, n, n, &alpha, fake, n, n * n, fake, n, n * n, &beta, fake, n,
+                                        n * n, 3);
+  printf("APP strided_64 status=%d\n", st);
+  st = rocblas_zgemm_strided_batched_64(h, 111, 111, n, n, n, zalpha, fake, n, n * n, fake, n, n * n, zbeta, fake, n,
+                                        n * n, 2);
+  printf("APP zstrided_64 status=%d\n", st);
+  st = rocblas_gemm_strided_batched_ex_64(h, 111, 111, n, n, n, zalpha, fake, 153, n, n * n, fake, 153, n, n * n, zbeta,
+                                          fake, 153, n, n * n, fake, 153, n, n * n, 2, 153, 0, 0, 0);
+  printf("APP strided_ex_64 status=%d\n", st);
   rocblas_destroy_handle(h);
   return 0;
 }
@@ -170,6 +243,16 @@ EXPECT_PASSTHROUGH = textwrap.dedent("""\
     APP zstrided status=0
     STUB gemm_strided_batched_ex m={n} n={n} k={n} types=152,152,152,152 strides={nn},{nn},{nn},{nn} batch=4 compute=152
     APP strided_ex status=0
+    STUB zgemm_64 m={n} n={n} k={n}
+    APP zgemm_64 status=0
+    STUB gemm_ex_64 m={n} n={n} k={n} types=152,152,152,152 compute=152
+    APP gemm_ex_64 status=0
+    STUB dgemm_strided_batched_64 m={n} n={n} k={n} strides={nn},{nn},{nn} batch=3
+    APP strided_64 status=0
+    STUB zgemm_strided_batched_64 m={n} n={n} k={n} strides={nn},{nn},{nn} batch=2
+    APP zstrided_64 status=0
+    STUB gemm_strided_batched_ex_64 m={n} n={n} k={n} types=153,153,153,153 strides={nn},{nn},{nn},{nn} batch=2 compute=153
+    APP strided_ex_64 status=0
     STUB destroy
     """)
 

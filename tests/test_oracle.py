@@ -247,6 +247,23 @@ def test_residual_curve_matches_survey():
     assert 50 < res[6] / res[7] < 250
 
 
+def test_baseline_config_c1_on_the_cpu_oracle():
+    """BASELINE.json configs[0] verbatim: fp64_int8_6, M=N=K=512, U[-1,1), split + INT8 GEMM + accumulate on the CPU.
+    Both summation orders; the residual sits where six 7-bit slices put it (~1e-11), and the diagonal
+    grouping (what the HIP kernel computes, checked bit for bit in tests/test_gpu_robustness.py) is no worse."""
+    m = n = k = 512
+    rng = np.random.default_rng(0)
+    a = operand("N", m, k, rng)
+    b = operand("N", k, n, rng)
+    res = {}
+    for order in (O.ORDER_REFERENCE, O.ORDER_DIAGONAL):
+        c = ColMajor(m, n)
+        assert O.gemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c.view, 6, order) == 0
+        res[order] = O.relative_residual_sampled("N", "N", m, n, k, a.view, b.view, c.view, ns=4096)
+    assert 1e-12 < res[O.ORDER_REFERENCE] < 1e-10, res
+    assert res[O.ORDER_DIAGONAL] <= 1.01 * res[O.ORDER_REFERENCE]
+
+
 @pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
 def test_reference_ci_gate_on_cpu(op_a, op_b):
     """test/main_test.cu:702-746 at full size for S=8 (the weakest gated mode), both summation orders"""

@@ -67,12 +67,24 @@ static float run_throttled(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e
 }
 
 // wide kernel (one 4-wave workgroup per CU, WA blocks per wave)
-template <int S, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL = 6>
+template <int S, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL = 6, bool MIX = false>
 static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   constexpr int NA = (VARW & VARW_NA3) ? 3 : 2;
   constexpr size_t lds = (size_t)(NA * WA + 2 * 4) * S * FRAG_BYTES;
   SliceGemmArgs a = a0;
   a.tiles_m = (a.M + 32 * WA - 1) / (32 * WA);
+  a.tiles_m2 = 0;
+  if (MIX) { // as many (WA-1)-block rows as make the big region a whole number of 256-CU rounds (8192: 80 + 8)
+    const uint32_t rows32 = (a.M + 31) / 32;
+    for (uint32_t n2 = 0; n2 * (WA - 1) <= rows32; n2++) {
+      const uint32_t n3 = (rows32 - n2 * (WA - 1) + WA - 1) / WA;
+      if ((n3 * ((a.N + 127) / 128)) % 256 == 0 && n3 * WA + n2 * (WA - 1) == rows32) {
+        a.tiles_m = n3;
+        a.tiles_m2 = n2;
+        break;
+      }
+    }
+  }
   a.tiles_n = (a.N + 127) / 128;
   a.rba = (uint32_t)row_blocks_padded(a.M);
   static bool done = false;
@@ -83,7 +95,7 @@ static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEv
   }
   CK(hipMemsetAsync(a.phase, 0, 8 * 256, st));
   CK(hipEventRecord(e0, st));
-  hipLaunchKernelGGL((slice_gemm_w_kernel<S, 0, S, WA, VARW, STAG, DMA0, DMAE, TAIL>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((slice_gemm_w_kernel<S, 0, S, WA, VARW, STAG, DMA0, DMAE, TAIL>), dim3((a.tiles_m + a.tiles_m2) * a.tiles_n), dim3(256), lds, st, a);
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
   CK(hipGetLastError());
@@ -150,16 +162,14 @@ int main(int argc, char **argv) {
   std::vector<Var> vars = {
       {"shipped 64x64 + throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
       {"wide 96x128 pd2", run_w<S, 3, VARW_NA3>, false, {}},
-      {"wide 96x128 pd2 stag16", run_w<S, 3, VARW_NA3, 16>, false, {}},
-      {"wide 96x128 pd2 stag8", run_w<S, 3, VARW_NA3, 8>, false, {}},
-      {"wide 96x128 pd2 dma every 2", run_w<S, 3, VARW_NA3, 0, 9, 2>, false, {}},
-      {"wide 96x128 pd2 dma every 7", run_w<S, 3, VARW_NA3, 0, 9, 7>, false, {}},
-      {"wide 96x128 pd2 tail 10", run_w<S, 3, VARW_NA3, 0, 9, 4, 10>, false, {}},
+      {"wide 96x128 pd2 mixed heights", run_w<S, 3, VARW_NA3, 0, -1, 4, 6, true>, false, {}},
+            {"wide 96x128 pd2 band 4x8", run_w<S, 3, VARW_NA3 | VARW_BAND4>, false, {}},
+      {"wide 96x128 pd2 band 16x2", run_w<S, 3, VARW_NA3 | VARW_BAND16>, false, {}},
+      {"wide 96x128 pd2 tail 3", run_w<S, 3, VARW_NA3, 0, -1, 4, 3>, false, {}},
+      {"wide 96x128 pd2 dma0 1", run_w<S, 3, VARW_NA3, 0, 1, 4>, false, {}},
       {"wide 96x128 pd1", run_w<S, 3, 0>, false, {}},
-      {"wide 64x128 pd2", run_w<S, 2, VARW_NA3>, false, {}},
       {"wide 96x128 no-global", run_w<S, 3, VARW_NA3 | VARW_NO_GLOBAL>, false, {}},
       {"wide 96x128 mfma-only rand", run_w<S, 3, VARW_NA3 | VARW_MFMA_ONLY>, false, {}},
-      {"64x64 no-global", run<S, VAR_NO_GLOBAL>, false, {}},
       {"64x64 mfma-only random regs", run<S, VAR_MFMA_ONLY | VAR_RAND_REGS>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
@@ -176,13 +186,47 @@ int main(int argc, char **argv) {
       if (which == 0) run_throttled<S, VAR_SHIPPED>(a, st, e0, e1);
       if (which == 1) run_w<S, 3, VARW_NA3>(a, st, e0, e1);
       if (which == 2) run_w<S, 3, 0>(a, st, e0, e1);
-      if (which == 3) run_w<S, 3, VARW_NA3, 16>(a, st, e0, e1);
-      if (which == 4) run_w<S, 2, VARW_NA3>(a, st, e0, e1);
+      if (which == 3) run_w<S, 3, VARW_NA3, 0, -1, 4, 6, true>(a, st, e0, e1);
+      if (which == 4) run_w<S, 3, VARW_NA3>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
       for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
       std::printf("check variant %d vs plain loop: %zu mismatching elements of %zu\n", which, bad, M * N);
     }
+  }
+  { // cycle stamps of the wide kernel (VARW_TRACE): where a k-step spends its time
+    uint32_t *tr;
+    const size_t ntr = 32 * 4 * 8 * 8;
+    CK(hipMalloc(&tr, ntr * 4));
+    CK(hipMemset(tr, 0, ntr * 4));
+    SliceGemmArgs b = a;
+    b.acc = reinterpret_cast<double *>(tr);
+    run_w<S, 3, VARW_NA3 | VARW_TRACE>(b, st, e0, e1);
+    std::vector<uint32_t> h(ntr);
+    CK(hipMemcpy(h.data(), tr, ntr * 4, hipMemcpyDeviceToHost));
+    auto d = [](uint32_t x, uint32_t y) { return (double)(uint32_t)(y - x); };
+    double sum[8] = {0};
+    int cnt = 0;
+    for (int bw = 0; bw < 32 * 4; bw++)
+      for (int stp = 0; stp + 1 < 8; stp++) {
+        const uint32_t *t = &h[(bw * 8 + stp) * 8], *tn = t + 8;
+        if (!t[0] || !tn[0]) continue;
+        sum[0] += d(t[5], t[0]);   // step start -> X
+        sum[1] += d(t[0], t[1]);   // vmcnt wait
+        sum[2] += d(t[1], t[2]);   // lgkmcnt(0)
+        sum[3] += d(t[2], t[3]);   // barrier
+        sum[4] += d(t[3], t[4]);   // X -> step end (refresh reads + TAIL MFMAs)
+        sum[5] += d(t[5], tn[5]);  // whole step
+        sum[6] += d(t[6], t[7]);   // one copy (M0 + issue)
+        cnt++;
+      }
+    if (cnt)
+      std::printf("wide trace (%d samples, shader cycles): step %.0f = start->X %.0f + vmcnt %.0f + lgkmcnt %.0f + barrier %.0f "
+                  "+ X->end %.0f ; one copy issue %.0f\n",
+                  cnt, sum[5] / cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[6] / cnt);
+    else
+      std::printf("wide trace: no samples \n");
+    CK(hipFree(tr));
   }
   const double ops = 45.0 * 2.0 * M * N * K;
   std::printf("M=%zu N=%zu K=%zu S=%d rounds=%d  (TOPS = 45*2*MNK / t)\n", M, N, K, S, rounds);

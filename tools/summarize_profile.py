@@ -58,7 +58,7 @@ def main(src, dst, workload="fp64_int8_9, M=8192 N=8192 K=8192, op N/N"):
     import json
     best = None
     for k in agg:
-        if "slice_gemm_kernel" in k and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+        if "slice_gemm" in k and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
             c = {n: sum(v) / len(v) for n, v in agg[k].items()}
             t = dict(kernel=k.split("(")[0], fetch_bytes_corrected=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024)
             t["hbm_bytes_per_launch"] = t["fetch_bytes_corrected"] + t["write_bytes"]
