@@ -69,6 +69,23 @@ hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t 
 hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, int8_t *planes,
                       double *max_exp, hipStream_t stream, const Batch &batch = Batch());
 
+// One-pass split (split.hip: split_fused_kernel): up to 4 operand views x `batch` matrices in ONE launch, no exponent
+// workspace.  For operands small enough that the re-read of a 32-row strip hits in L2 / Infinity Cache.
+struct SplitJob {
+  OperandView v;
+  int8_t *planes;
+  double *max_exp;
+  long long in_stride; // batch stride of the input in doubles
+};
+struct SplitJobs {
+  SplitJob job[4];
+  uint32_t rb_count[4]; // padded row-blocks per view
+  int count, S, L;
+  size_t ws_stride;
+};
+hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch = 1,
+                              size_t ws_stride = 0);
+
 // tiled planes -> reference layout [S][rows][ldo] (test hook for ozimmu_hip_split_int8)
 hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int8_t *out, size_t ldo,
                          hipStream_t stream);

@@ -17,8 +17,9 @@
 //    thread (src/split.cu:176-184);
 //  * no device synchronisation (the reference calls cudaDeviceSynchronize per operand, :261).
 //
-// Algorithmic HBM bytes: (8 + S) per element (one read, S slice bytes); this implementation reads
-// the operand twice (row-max pass + cut pass): 16 + S.
+// Algorithmic HBM bytes: (8 + S) per element (one read, S slice bytes).  Operands that stay cache resident are split
+// in one pass (split_fused_kernel: 8 + S from HBM); larger ones in two streaming passes (row-max pass + cut pass:
+// 16 + S).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -176,6 +177,70 @@ __device__ __forceinline__ void load_block(const double *__restrict__ in, size_t
   arrange_block<KCONTIG>(t, lane, tile, v);
 }
 
+// ---- the cut itself: 16 k values of one row -> S x 16 slice bytes (src/split.cu:154-185) ------------------------------
+// e = the row's maximum exponent field.  e == 0: zero/subnormal row -> max_exp 0, zero slices (reference: 0*2 = 0,
+// src/split.cu:191); e >= 0x7FE: Inf/NaN in the row, or 2^(e+1) not representable -> poisoned row (max_exp = NaN).
+__device__ __forceinline__ double max_exp_of(unsigned e) {
+  const bool live = e != 0u && e < 0x7FEu;
+  const unsigned long long bits = live ? ((unsigned long long)(e + 1) << 52) : (e == 0u ? 0ull : 0x7FF8000000000000ull);
+  return __longlong_as_double((long long)bits);
+}
+
+// out: this lane's 16 bytes of slice 0 inside the fragment block run (slice s follows FRAG_BYTES * s later)
+__device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e, int S, int L, int8_t *out) {
+  const bool live = e != 0u && e < 0x7FEu;
+  // 128-bit shifted mantissa (hi:lo) = (m53 << 75) >> off, per element (src/split.cu:163-175)
+  unsigned long long hi[16], lo[16];
+  unsigned negmask[4] = {0, 0, 0, 0}; // per packed word: 0xFF in the bytes of negative elements
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const unsigned long long bq = (unsigned long long)__double_as_longlong(v[q]);
+    const unsigned f = (unsigned)(bq >> 52) & 0x7FFu;
+    const unsigned long long m53 = (bq & MANT_MASK) | (f ? (1ull << 52) : 0ull);
+    const unsigned ef = f ? f : 1u; // subnormal: exponent of field 1 (fix of SURVEY §8a quirk 7)
+    const unsigned off = e + 1u - ef; // >= 1 for live rows
+    const unsigned long long V = live ? (m53 << 11) : 0ull;
+    unsigned long long h, l;
+    if (off < 64u) {
+      h = V >> off;
+      l = V << (64u - off); // off >= 1
+    } else if (off < 128u) {
+      h = 0;
+      l = V >> (off - 64u);
+    } else {
+      h = 0;
+      l = 0;
+    }
+    hi[q] = h;
+    lo[q] = l;
+    if (bq >> 63) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
+  }
+
+  const unsigned long long mask = (1ull << L) - 1ull;
+  for (int s = 0; s < S; s++) {
+    const int p = 128 - (s + 1) * L; // low bit of slice s inside (hi:lo); p >= 2 since S*L <= 126
+    unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      unsigned long long x;
+      if (p >= 64)
+        x = hi[q] >> (p - 64);
+      else
+        x = (lo[q] >> p) | (hi[q] << (64 - p));
+      w[q >> 2] |= (unsigned)(x & mask) << (8 * (q & 3));
+    }
+    uint4 o;
+    unsigned *op = &o.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      // per-byte two's complement of the bytes selected by negmask (values <= 127, SWAR, no carries)
+      const unsigned m = negmask[i], tt = w[i] ^ m;
+      op[i] = ((tt & 0x7F7F7F7Fu) + (m & 0x01010101u)) ^ (tt & 0x80808080u);
+    }
+    *(uint4 *)(out + (size_t)s * FRAG_BYTES) = o;
+  }
+}
+
 // ---- pass 2: cut ---------------------------------------------------------------------------------------
 // One wave cuts `strip` consecutive blocks along the memory-contiguous axis of the operand.  k-contiguous operands
 // (PREFETCH): the loads of the next block are issued before the current one is cut -- with the LDS transpose the
@@ -230,66 +295,8 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
     const int r = lane & 31;
     const size_t rg = rb * 32 + r;
     const unsigned e = rg < rows ? exps[rg] : 0u;
-    // e == 0: zero/subnormal row -> max_exp 0, zero slices (reference: 0*2 = 0, src/split.cu:191)
-    // e >= 0x7FE: Inf/NaN in the row, or 2^(e+1) not representable -> poisoned row (max_exp = NaN)
-    const bool live = e != 0u && e < 0x7FEu;
-    if (kb == 0 && lane < 32 && rg < rows) {
-      const unsigned long long bits =
-          live ? ((unsigned long long)(e + 1) << 52) : (e == 0u ? 0ull : 0x7FF8000000000000ull);
-      max_exp[rg] = __longlong_as_double((long long)bits);
-    }
-
-    // 128-bit shifted mantissa (hi:lo) = (m53 << 75) >> off, per element (src/split.cu:163-175)
-    unsigned long long hi[16], lo[16];
-    unsigned negmask[4] = {0, 0, 0, 0}; // per packed word: 0xFF in the bytes of negative elements
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const unsigned long long bq = (unsigned long long)__double_as_longlong(v[q]);
-      const unsigned f = (unsigned)(bq >> 52) & 0x7FFu;
-      const unsigned long long m53 = (bq & MANT_MASK) | (f ? (1ull << 52) : 0ull);
-      const unsigned ef = f ? f : 1u; // subnormal: exponent of field 1 (fix of SURVEY §8a quirk 7)
-      const unsigned off = e + 1u - ef; // >= 1 for live rows
-      const unsigned long long V = live ? (m53 << 11) : 0ull;
-      unsigned long long h, l;
-      if (off < 64u) {
-        h = V >> off;
-        l = V << (64u - off); // off >= 1
-      } else if (off < 128u) {
-        h = 0;
-        l = V >> (off - 64u);
-      } else {
-        h = 0;
-        l = 0;
-      }
-      hi[q] = h;
-      lo[q] = l;
-      if (bq >> 63) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
-    }
-
-    const unsigned long long mask = (1ull << L) - 1ull;
-    int8_t *out = planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16;
-    for (int s = 0; s < S; s++) {
-      const int p = 128 - (s + 1) * L; // low bit of slice s inside (hi:lo); p >= 2 since S*L <= 126
-      unsigned w[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        unsigned long long x;
-        if (p >= 64)
-          x = hi[q] >> (p - 64);
-        else
-          x = (lo[q] >> p) | (hi[q] << (64 - p));
-        w[q >> 2] |= (unsigned)(x & mask) << (8 * (q & 3));
-      }
-      uint4 o;
-      unsigned *op = &o.x;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        // per-byte two's complement of the bytes selected by negmask (values <= 127, SWAR, no carries)
-        const unsigned m = negmask[i], tt = w[i] ^ m;
-        op[i] = ((tt & 0x7F7F7F7Fu) + (m & 0x01010101u)) ^ (tt & 0x80808080u);
-      }
-      *(uint4 *)(out + (size_t)s * FRAG_BYTES) = o;
-    }
+    if (kb == 0 && lane < 32 && rg < rows) max_exp[rg] = max_exp_of(e);
+    cut_and_store(v, e, S, L, planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16);
   }
 }
 
@@ -308,6 +315,128 @@ hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, 
   else
     hipLaunchKernelGGL(cut_kernel<false>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
                        exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+  return hipGetLastError();
+}
+
+// ---- one-pass split for operands that stay cache resident ------------------------------------------------------------
+// One workgroup owns a 32-row block for ALL of K: phase 1 finds the 32 row maxima (kept in LDS), phase 2 re-reads the
+// strip -- 32 x K x 8 bytes, L2 / Infinity-Cache hits as long as the operand is small against the 256 MiB cache -- and
+// cuts it.  HBM sees the operand once (algorithmic 8 + S bytes per element instead of 16 + S), and the exponent
+// words, their memset and the atomics of the two-pass form disappear: up to four operand views (A and B of a real
+// product, Re/Im of both for a complex one) x the matrices of a batch are split by ONE launch, which is what small
+// problems -- bounded by launch gaps, not bandwidth -- need.
+template <bool KCONTIG>
+__device__ __forceinline__ void split_strip(const SplitJob &j, int S, int L, size_t rb, double (*tile)[33],
+                                            unsigned (*red)[32]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t KB = (j.v.K + FRAG_K - 1) / FRAG_K;
+  const double *in = j.v.in;
+  const size_t rows = j.v.rows, K = j.v.K, sr = j.v.stride_r, sk = j.v.stride_k;
+  // phase 1: exponent maxima.  Row-contiguous: a lane sees 16 k of its own row (lane & 31); k-contiguous: element `it`
+  // of a lane belongs to row 2*it + (lane >> 5), reduced across lanes once at the end.
+  unsigned e_rc = 0, e_kc[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) e_kc[q] = 0;
+  if (rb * 32 < rows) {
+    // a strip is walked by only 4 waves: keep DEPTH blocks of loads in flight per wave (the pass is latency bound)
+    constexpr int DEPTH = 4;
+    for (size_t kb0 = wave; kb0 < KB; kb0 += 4 * DEPTH) {
+      double t[DEPTH][16];
+#pragma unroll
+      for (int d = 0; d < DEPTH; d++)
+        if (kb0 + 4 * d < KB) fetch_block<KCONTIG>(in, rows, K, sr, sk, rb, kb0 + 4 * d, lane, t[d]);
+#pragma unroll
+      for (int d = 0; d < DEPTH; d++)
+        if (kb0 + 4 * d < KB) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const unsigned x = exp_field(t[d][q]);
+            if constexpr (KCONTIG)
+              e_kc[q] = x > e_kc[q] ? x : e_kc[q];
+            else
+              e_rc = x > e_rc ? x : e_rc;
+          }
+        }
+    }
+  }
+  if constexpr (KCONTIG) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      unsigned x = e_kc[q];
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) { // within the half-wave that shares (lane >> 5)
+        const unsigned o = __shfl_xor(x, off, 64);
+        x = o > x ? o : x;
+      }
+      if ((lane & 31) == 0) red[wave][2 * q + (lane >> 5)] = x;
+    }
+  } else {
+    const unsigned o = __shfl_xor(e_rc, 32, 64);
+    e_rc = o > e_rc ? o : e_rc;
+    if (lane < 32) red[wave][lane] = e_rc;
+  }
+  __syncthreads();
+  const int r = lane & 31;
+  unsigned e = red[0][r];
+#pragma unroll
+  for (int w = 1; w < 4; w++) e = red[w][r] > e ? red[w][r] : e;
+  const size_t rg = rb * 32 + r;
+  if (wave == 0 && lane < 32 && rg < rows) j.max_exp[rg] = max_exp_of(e);
+  // phase 2: cut (rows >= `rows` of the padded planes and k >= K read as zeros -> zero slices); the next block's
+  // loads are in flight while the current one is cut
+  double t[16];
+  if ((size_t)wave < KB) fetch_block<KCONTIG>(in, rows, K, sr, sk, rb, wave, lane, t);
+#pragma unroll 1
+  for (size_t kb = wave; kb < KB; kb += 4) {
+    double v[16];
+    arrange_block<KCONTIG>(t, lane, tile, v);
+    if (kb + 4 < KB) fetch_block<KCONTIG>(in, rows, K, sr, sk, rb, kb + 4, lane, t);
+    cut_and_store(v, e, S, L, j.planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16);
+  }
+}
+
+__global__ __launch_bounds__(256) void split_fused_kernel(const SplitJobs jobs) {
+  __shared__ double tiles[4][32][33];
+  __shared__ unsigned red[4][32];
+  // blockIdx.x: row-block over all views (each padded to TILE_ROWS), blockIdx.z: matrix of the batch
+  int ji = 0;
+  uint32_t rb = blockIdx.x;
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    if (ji + 1 < jobs.count && rb >= jobs.rb_count[ji]) {
+      rb -= jobs.rb_count[ji];
+      ji++;
+    }
+  SplitJob j = jobs.job[0];
+  if (ji == 1) j = jobs.job[1];
+  if (ji == 2) j = jobs.job[2];
+  if (ji == 3) j = jobs.job[3];
+  j.v.in += (long long)blockIdx.z * j.in_stride;
+  j.planes += (size_t)blockIdx.z * jobs.ws_stride;
+  j.max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + (size_t)blockIdx.z * jobs.ws_stride);
+  const int wave = threadIdx.x >> 6;
+  if (j.v.stride_k < j.v.stride_r)
+    split_strip<true>(j, jobs.S, jobs.L, rb, tiles[wave], red);
+  else
+    split_strip<false>(j, jobs.S, jobs.L, rb, tiles[wave], red);
+}
+
+hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch,
+                              size_t ws_stride) {
+  if (count < 1 || count > 4) return hipErrorInvalidValue;
+  SplitJobs jobs{};
+  jobs.count = count;
+  jobs.S = S;
+  jobs.L = L;
+  jobs.ws_stride = ws_stride;
+  uint32_t total = 0;
+  for (int i = 0; i < count; i++) {
+    jobs.job[i] = job[i];
+    jobs.rb_count[i] = (uint32_t)row_blocks_padded(job[i].v.rows);
+    total += jobs.rb_count[i];
+  }
+  if (total == 0 || batch == 0) return hipSuccess;
+  hipLaunchKernelGGL(split_fused_kernel, dim3(total, 1, batch), dim3(256), 0, stream, jobs);
   return hipGetLastError();
 }
 

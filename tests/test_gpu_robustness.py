@@ -151,8 +151,10 @@ def test_injected_launch_failure_real_leaves_c_untouched(oz, monkeypatch):
     monkeypatch.setenv("OZIMMU_HIP_TEST_FAIL_LAUNCH", "1")
     monkeypatch.setenv("OZIMMU_ERROR", "0")
     assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_9") == 3
-    monkeypatch.setenv("OZIMMU_HIP_TEST_FAIL_LAUNCH", "2")           # second launch of the two diagonal passes
-    assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_14") == 3
+    assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_14") == 3   # two diagonal passes
+    monkeypatch.setenv("OZIMMU_HIP_TEST_FAIL_LAUNCH", "2")           # second K chunk (k > INT32-safe pass length)
+    ak = torch.rand(20000, n, dtype=torch.float64, device="cuda")
+    assert m_.gemm(h, "T", "N", n, n, 20000, 1.0, ak, 20000, ak, 20000, 0.5, c, n, "fp64_int8_9") == 3
     _sync()
     assert (c == 7.0).all()
     monkeypatch.delenv("OZIMMU_HIP_TEST_FAIL_LAUNCH")
@@ -179,7 +181,7 @@ PRELOAD_FAIL = r"""
 int main() {
   const int n = 256;
   std::vector<double> A(n * n, 0.5), C(n * n, 2.0), out(n * n);
-  std::vector<rocblas_double_complex> ZA(n * n, rocblas_double_complex(0.5, 0.25)), ZC(n * n, rocblas_double_complex(2.0, 1.0)), zout(n * n);
+  std::vector<rocblas_double_complex> ZA(n * n, rocblas_double_complex{0.5, 0.25}), ZC(n * n, rocblas_double_complex{2.0, 1.0}), zout(n * n);
   double *dA, *dC; rocblas_double_complex *zA, *zC;
   hipMalloc(&dA, n * n * 8); hipMalloc(&dC, n * n * 8); hipMalloc(&zA, n * n * 16); hipMalloc(&zC, n * n * 16);
   hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice); hipMemcpy(dC, C.data(), n * n * 8, hipMemcpyHostToDevice);
@@ -190,7 +192,7 @@ int main() {
   hipDeviceSynchronize();
   hipMemcpy(out.data(), dC, n * n * 8, hipMemcpyDeviceToHost);
   printf("DGEMM status=%d c00=%.6f\n", (int)st, out[0]);          // 0.25*256 + 0.5*2 = 65
-  const rocblas_double_complex za(1.0, 0.0), zb(0.5, 0.0);
+  const rocblas_double_complex za{1.0, 0.0}, zb{0.5, 0.0};
   st = rocblas_zgemm(h, rocblas_operation_none, rocblas_operation_none, n, n, n, &za, zA, n, zA, n, &zb, zC, n);
   hipDeviceSynchronize();
   printf("ZGEMM status=%d\n", (int)st);
