@@ -162,10 +162,47 @@ static int check_address_alignment(const void *p, size_t elem, const char *mat) 
 }
 
 // split of one operand into the workspace; stream ordered
+// Two streaming passes (row maxima, then cut).  OZIMMU_HIP_SPLIT_BAND_BYTES > 0 walks the operand in row bands of that
+// size, so that the cut pass of a band re-reads what its row-max pass just brought into the Infinity Cache.  Measured
+// with 64 MiB bands it LOSES (8192^3: 16.90 vs 16.69 ms per GEMM, 6144^3: 7.34 vs 7.22: more, smaller launches cost more
+// than the cache hits return), so the default is one band; the knob stays for experiments and the parity tests.
 static bool run_split(ozimmu_hip_handle_t h, const OperandView &v, uint32_t *exps, int S, int L,
                       int8_t *planes, double *max_exp, const Batch &batch = Batch()) {
-  return hip_ok(launch_row_max_exp(v, exps, h->stream, batch), "row_max_exp") &&
-         hip_ok(launch_cut(v, exps, S, L, planes, max_exp, h->stream, batch), "cut");
+  size_t band_bytes = 0;
+  if (const char *e = getenv("OZIMMU_HIP_SPLIT_BAND_BYTES")) band_bytes = std::strtoull(e, nullptr, 10);
+  const size_t row_bytes = 8 * std::max<size_t>(v.K, 1) * std::max<uint32_t>(batch.count, 1);
+  size_t band_rows = band_bytes ? std::max<size_t>(TILE_ROWS, band_bytes / row_bytes / TILE_ROWS * TILE_ROWS) : v.rows;
+  if (band_rows >= v.rows || v.rows * row_bytes <= 2 * band_bytes) band_rows = v.rows;
+  const size_t KB = k_blocks(v.K);
+  for (size_t r0 = 0; r0 < v.rows; r0 += band_rows) {
+    OperandView b = v;
+    b.in = v.in + r0 * v.stride_r;
+    b.rows = std::min(band_rows, v.rows - r0);
+    int8_t *pl = planes + (r0 / FRAG_ROWS) * KB * (size_t)S * FRAG_BYTES;
+    if (!hip_ok(launch_row_max_exp(b, exps + r0, h->stream, batch), "row_max_exp") ||
+        !hip_ok(launch_cut(b, exps + r0, S, L, pl, max_exp + r0, h->stream, batch), "cut"))
+      return false;
+  }
+  return true;
+}
+
+// One-pass split (split.hip: split_fused_kernel): a workgroup owns a 32-row strip for all of K, so HBM sees the operand
+// once and a GEMM call needs 2 launches instead of 6 -- but a strip is walked by only 4 waves, and measured it loses to
+// the two streaming passes at every size (1024^2: +29 us, 2048^2: +59 us per GEMM; tools/bench_kernel_choice.py), so it
+// is OFF unless OZIMMU_HIP_SPLIT_ONE_PASS_BYTES raises the limit (parity tests run both forms).
+static bool one_pass_split(size_t operand_bytes) {
+  size_t limit = 0;
+  if (const char *e = getenv("OZIMMU_HIP_SPLIT_ONE_PASS_BYTES")) limit = std::strtoull(e, nullptr, 10);
+  return operand_bytes <= limit;
+}
+
+// Problems whose operands total at most this many bytes split all their operand views with ONE launch per pass
+// (row_max_kernel / cut_multi_kernel): they are bounded by launch gaps.  Larger ones keep one launch per view (each
+// layout at its own occupancy) and walk row bands.  OZIMMU_HIP_SPLIT_MULTI_BYTES overrides (0: never).
+static bool multi_view_split(size_t operand_bytes) {
+  size_t limit = (size_t)512 << 20;
+  if (const char *e = getenv("OZIMMU_HIP_SPLIT_MULTI_BYTES")) limit = std::strtoull(e, nullptr, 10);
+  return operand_bytes <= limit;
 }
 
 // a strided batch in BLAS terms: matrix i of an operand starts stride * i ELEMENTS after matrix 0
@@ -225,10 +262,29 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  if (!zero_slot_heads(h, w.exps_a, w.exps_bytes, slot, bs.count)) return 3;
-  if (!run_split(h, view_A(op_A, m, k, a, lda), w.exps_a, S, L, w.planes_a, w.ea, ba)) return 3;
-  if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
-  if (!run_split(h, view_B(op_B, k, n, b, ldb), w.exps_b, S, L, w.planes_b, w.eb, bb)) return 3;
+  const bool use_phase = bs.count == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false);
+  if (one_pass_split(8 * (m + n) * k * bs.count)) {
+    // both operands (and every matrix of the batch) in one launch; only the phase hint words need zeroing
+    if (use_phase && !hip_ok(hipMemsetAsync(w.phase, 0, 8 * 256, h->stream), "memset")) return 3;
+    const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, nullptr},
+                              {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, nullptr}};
+    if (!hip_ok(launch_split_fused(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot), "split")) return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3; // split_A + split_B -> split_A
+  } else if (multi_view_split(8 * (m + n) * k * bs.count)) {
+    // A and B in one launch per pass: memset, row maxima, cut, GEMM = 4 launches (in the stage report the row-max
+    // pass is booked under split_A and the cut pass under split_B)
+    if (!zero_slot_heads(h, w.exps_a, w.exps_bytes, slot, bs.count)) return 3;
+    const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, w.exps_a},
+                              {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, w.exps_b}};
+    if (!hip_ok(launch_row_max_multi(jobs, 2, h->stream, (uint32_t)bs.count, slot), "row_max_exp")) return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+    if (!hip_ok(launch_cut_multi(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot), "cut")) return 3;
+  } else {
+    if (!zero_slot_heads(h, w.exps_a, w.exps_bytes, slot, bs.count)) return 3;
+    if (!run_split(h, view_A(op_A, m, k, a, lda), w.exps_a, S, L, w.planes_a, w.ea, ba)) return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+    if (!run_split(h, view_B(op_B, k, n, b, ldb), w.exps_b, S, L, w.planes_b, w.eb, bb)) return 3;
+  }
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
 
   SliceGemmArgs g{};
@@ -248,7 +304,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   g.ldc = ldc;
   g.acc = w.acc;
   // the phase hint coordinates the workgroups of ONE product: a batch runs without it
-  g.phase = (bs.count > 1 || env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false)) ? nullptr : w.phase;
+  g.phase = use_phase ? w.phase : nullptr;
   g.throttle = bs.count > 1 ? 0u : throttle_for(m, n, k);
   g.batch = (uint32_t)bs.count;
   g.ws_stride = slot;
@@ -342,14 +398,34 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  if (!zero_slot_heads(h, w.exps_a[0], w.exps_bytes, slot, bs.count)) return 3;
-  for (int part = 0; part < 2; part++)
-    if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), w.exps_a[part], S, L, w.planes_a[part], w.ea[part], ba))
-      return 3;
-  if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
-  for (int part = 0; part < 2; part++)
-    if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), w.exps_b[part], S, L, w.planes_b[part], w.eb[part], bb))
-      return 3;
+  const bool use_phase = bs.count == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false);
+  if (one_pass_split(16 * (m + n) * k * bs.count)) {
+    if (use_phase && !hip_ok(hipMemsetAsync(w.phase, 0, 8 * 256, h->stream), "memset")) return 3;
+    const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, nullptr},
+                              {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, nullptr},
+                              {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, nullptr},
+                              {view_B_part(op_B, k, n, b, ldb, 1), w.planes_b[1], w.eb[1], bb.in_stride, nullptr}};
+    if (!hip_ok(launch_split_fused(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot), "split")) return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+  } else if (multi_view_split(16 * (m + n) * k * bs.count)) {
+    if (!zero_slot_heads(h, w.exps_a[0], w.exps_bytes, slot, bs.count)) return 3;
+    const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, w.exps_a[0]},
+                              {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, w.exps_a[1]},
+                              {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, w.exps_b[0]},
+                              {view_B_part(op_B, k, n, b, ldb, 1), w.planes_b[1], w.eb[1], bb.in_stride, w.exps_b[1]}};
+    if (!hip_ok(launch_row_max_multi(jobs, 4, h->stream, (uint32_t)bs.count, slot), "row_max_exp")) return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+    if (!hip_ok(launch_cut_multi(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot), "cut")) return 3;
+  } else {
+    if (!zero_slot_heads(h, w.exps_a[0], w.exps_bytes, slot, bs.count)) return 3;
+    for (int part = 0; part < 2; part++)
+      if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), w.exps_a[part], S, L, w.planes_a[part], w.ea[part], ba))
+        return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+    for (int part = 0; part < 2; part++)
+      if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), w.exps_b[part], S, L, w.planes_b[part], w.eb[part], bb))
+        return 3;
+  }
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
 
   // From here on C is modified in place (beta scaling, then four accumulating products): a failure below is reported
@@ -384,7 +460,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     g.c = c;
     g.ldc = ldc;
     g.acc = w.acc;
-    g.phase = (bs.count > 1 || env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false)) ? nullptr : w.phase;
+    g.phase = use_phase ? w.phase : nullptr;
     g.throttle = bs.count > 1 ? 0u : throttle_for(m, n, k);
     g.batch = (uint32_t)bs.count;
     g.ws_stride = slot;
@@ -919,7 +995,13 @@ int ozimmu_hip_split_int8(ozimmu_hip_handle_t h, int8_t *out_ptr, uint32_t ldo, 
   bool ok = hip_ok(hipMemsetAsync(exps, 0, exps_bytes, h->stream), "memset");
   if (v.K == 0) // nothing to cut: max_exp of an empty row is 0
     ok = ok && hip_ok(hipMemsetAsync(max_exp_ptr, 0, 8 * v.rows, h->stream), "memset");
-  ok = ok && run_split(h, v, exps, (int)num_split, (int)bits_per_int8, planes, max_exp_ptr) &&
+  if (one_pass_split(8 * v.rows * v.K)) { // the same kernel choice as the GEMM path makes for this operand size
+    const SplitJob job{v, planes, max_exp_ptr, 0, nullptr};
+    ok = ok && hip_ok(launch_split_fused(&job, 1, (int)num_split, (int)bits_per_int8, h->stream), "split");
+  } else {
+    ok = ok && run_split(h, v, exps, (int)num_split, (int)bits_per_int8, planes, max_exp_ptr);
+  }
+  ok = ok &&
        hip_ok(launch_untile(planes, v.rows, v.K, (int)num_split, out_ptr, ldo, h->stream), "untile");
   return ok ? 0 : 3;
 }

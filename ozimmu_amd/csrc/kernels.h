@@ -76,13 +76,20 @@ struct SplitJob {
   int8_t *planes;
   double *max_exp;
   long long in_stride; // batch stride of the input in doubles
+  uint32_t *exps;      // two-pass kernels: the view's row exponent words (zeroed before the row-max pass)
 };
 struct SplitJobs {
   SplitJob job[4];
-  uint32_t rb_count[4]; // padded row-blocks per view
+  uint32_t nblk[4]; // workgroups of each view in this launch
+  uint32_t nx[4];   // row_max: row groups per view (block = k chunk * nx + row group); cut: strip length
   int count, S, L;
   size_t ws_stride;
 };
+// the two streaming passes for up to 4 views x `batch` matrices in one launch each (small problems: launch bound)
+hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stream, uint32_t batch = 1,
+                                size_t ws_stride = 0);
+hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch = 1,
+                            size_t ws_stride = 0);
 hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch = 1,
                               size_t ws_stride = 0);
 

@@ -147,15 +147,17 @@ static WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) {
   return best;
 }
 
-// The wide kernel needs enough tiles to fill the CUs (a 96x128 tile is 3x the work of a 64x64 one); below that the
-// classic kernel's smaller tiles win.  OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements).
+// The wide kernel wins as soon as its tiles occupy half of the CUs (measured, fp64_int8_9 square sizes, tools/
+// bench_kernel_choice.py: 1536^3 = 192 tiles: 177 vs 211 us; 2048^3 339 vs 347; 3072^3 1006 vs 1124; 8192^3 16.9 vs
+// 19.5 ms; at 1024^3 its 88 tiles lose to the classic kernel's 256 of 64x64: 88 vs 77 us).
+// OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements, parity tests of both kernels on small shapes).
 static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu) {
   if (const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL")) {
     if (!std::strcmp(e, "wide")) return true;
     if (!std::strcmp(e, "classic")) return false;
   }
   const uint64_t wgs = (uint64_t)(pl.n_big + pl.n_small) * tn;
-  return wgs >= (uint64_t)ncu && pl.efficiency >= 0.80;
+  return 2 * wgs >= (uint64_t)ncu;
 }
 
 template <int S, int D0, int ND>

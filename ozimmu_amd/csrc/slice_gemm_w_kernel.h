@@ -437,6 +437,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const SliceGemmArgs p_in) {
   const SliceGemmArgs p = batch_view(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long wg_t0 = 0;
+  if constexpr ((VARW & VARW_TRACE) != 0) wg_t0 = wall_clock64();
   const uint32_t nbig = p.tiles_m * p.tiles_n, nsmall = p.tiles_m2 * p.tiles_n;
   const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
   const uint32_t nbig_x = (nbig >> 3) + (xcd < (nbig & 7u) ? 1u : 0u);
@@ -449,6 +451,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if constexpr (WA > 1) {
       band_order<BH>(xcd_run_start((xcd - (nbig & 7u)) & 7u, nsmall) + (idx - nbig_x), p.tiles_m2, p.tiles_n, r, c);
       w_tile<S, D0, ND, WA - 1, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * p.tiles_m + (WA - 1) * r, c);
+    }
+  }
+  if constexpr ((VARW & VARW_TRACE) != 0) { // per-workgroup placement and wall-clock span (100 MHz), after the step stamps
+    if (threadIdx.x == 0) {
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned long long *w = reinterpret_cast<unsigned long long *>(p.acc) + 4096 + (size_t)blockIdx.x * 3;
+      w[0] = ((unsigned long long)(xcc & 0xf) << 32) | (hw & 0xff00u);
+      w[1] = wg_t0;
+      w[2] = wall_clock64();
     }
   }
 }

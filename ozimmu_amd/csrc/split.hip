@@ -44,15 +44,12 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 
 // ---- pass 1: per-row maximum exponent field ---------------------------------------------------------
 // k-contiguous operand: element (r,k) at in[r*ld + k].  One wave per row segment, lanes along k.
-__global__ __launch_bounds__(256) void row_max_kcontig_kernel(const double *__restrict__ in, size_t rows,
-                                                              size_t K, size_t sr, size_t sk, uint32_t *exps,
-                                                              unsigned kchunk, long long in_stride, size_t ws_stride) {
-  in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
-  exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(exps) + (size_t)blockIdx.z * ws_stride);
+__device__ __forceinline__ void row_max_kcontig(const double *__restrict__ in, size_t rows, size_t K, size_t sr,
+                                                size_t sk, uint32_t *exps, unsigned kchunk, size_t bx, size_t by) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t r = (size_t)blockIdx.x * 4 + wave;
+  const size_t r = bx * 4 + wave;
   if (r >= rows) return;
-  const size_t k0 = (size_t)blockIdx.y * kchunk;
+  const size_t k0 = by * kchunk;
   const size_t k1 = k0 + kchunk < K ? k0 + kchunk : K;
   const double *p = in + r * sr;
   unsigned e = 0;
@@ -73,15 +70,12 @@ __global__ __launch_bounds__(256) void row_max_kcontig_kernel(const double *__re
 }
 
 // row-contiguous operand: element (r,k) at in[k*ld + r].  Lanes along r, the 4 waves interleave k.
-__global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__restrict__ in, size_t rows,
-                                                              size_t K, size_t sr, size_t sk, uint32_t *exps,
-                                                              unsigned kchunk, long long in_stride, size_t ws_stride) {
-  in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
-  exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(exps) + (size_t)blockIdx.z * ws_stride);
-  __shared__ unsigned red[4][64];
+__device__ __forceinline__ void row_max_rcontig(const double *__restrict__ in, size_t rows, size_t K, size_t sr,
+                                                size_t sk, uint32_t *exps, unsigned kchunk, size_t bx, size_t by,
+                                                unsigned (*red)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t r = (size_t)blockIdx.x * 64 + lane;
-  const size_t k0 = (size_t)blockIdx.y * kchunk;
+  const size_t r = bx * 64 + lane;
+  const size_t k0 = by * kchunk;
   const size_t k1 = k0 + kchunk < K ? k0 + kchunk : K;
   unsigned e = 0;
   if (r < rows) {
@@ -109,20 +103,58 @@ __global__ __launch_bounds__(256) void row_max_rcontig_kernel(const double *__re
   }
 }
 
-hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream, const Batch &b) {
-  if (v.rows == 0 || v.K == 0 || b.count == 0) return hipSuccess;
-  if (v.stride_k < v.stride_r) {
-    const unsigned kchunk = 8192;
-    dim3 grid((unsigned)((v.rows + 3) / 4), (unsigned)((v.K + kchunk - 1) / kchunk), b.count);
-    hipLaunchKernelGGL(row_max_kcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, v.stride_k, exps, kchunk, b.in_stride, b.ws_stride);
-  } else {
-    const unsigned kchunk = 512;
-    dim3 grid((unsigned)((v.rows + 63) / 64), (unsigned)((v.K + kchunk - 1) / kchunk), b.count);
-    hipLaunchKernelGGL(row_max_rcontig_kernel, grid, dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, v.stride_k, exps, kchunk, b.in_stride, b.ws_stride);
+// Up to 4 operand views per launch (A and B of a product, or Re/Im of both): blockIdx.x enumerates the (row group,
+// k chunk) pairs of all views; blockIdx.z = matrix of a batch.  Small problems are bounded by launch gaps, not
+// bandwidth: one launch per pass instead of one per operand view.
+__global__ __launch_bounds__(256) void row_max_kernel(const SplitJobs jobs) {
+  __shared__ unsigned red[4][64];
+  int ji = 0;
+  uint32_t blk = blockIdx.x;
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    if (ji + 1 < jobs.count && blk >= jobs.nblk[ji]) {
+      blk -= jobs.nblk[ji];
+      ji++;
+    }
+  SplitJob j = jobs.job[0];
+  uint32_t nx = jobs.nx[0];
+  if (ji == 1) j = jobs.job[1], nx = jobs.nx[1];
+  if (ji == 2) j = jobs.job[2], nx = jobs.nx[2];
+  if (ji == 3) j = jobs.job[3], nx = jobs.nx[3];
+  const double *in = j.v.in + (long long)blockIdx.z * j.in_stride;
+  uint32_t *exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(j.exps) + (size_t)blockIdx.z * jobs.ws_stride);
+  const uint32_t bx = blk % nx, by = blk / nx;
+  if (j.v.stride_k < j.v.stride_r)
+    row_max_kcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, 8192u, bx, by);
+  else
+    row_max_rcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, 512u, bx, by, red);
+}
+
+hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stream, uint32_t batch, size_t ws_stride) {
+  if (count < 1 || count > 4) return hipErrorInvalidValue;
+  SplitJobs jobs{};
+  jobs.count = count;
+  jobs.ws_stride = ws_stride;
+  uint64_t total = 0;
+  for (int i = 0; i < count; i++) {
+    const OperandView &v = job[i].v;
+    jobs.job[i] = job[i];
+    const bool kc = v.stride_k < v.stride_r;
+    const unsigned kchunk = kc ? 8192u : 512u;
+    jobs.nx[i] = (uint32_t)(kc ? (v.rows + 3) / 4 : (v.rows + 63) / 64);
+    jobs.nblk[i] = (v.rows && v.K) ? jobs.nx[i] * (uint32_t)((v.K + kchunk - 1) / kchunk) : 0;
+    if (jobs.nx[i] == 0) jobs.nx[i] = 1;
+    total += jobs.nblk[i];
   }
+  if (total == 0 || batch == 0) return hipSuccess;
+  if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(row_max_kernel, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
   return hipGetLastError();
+}
+
+hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream, const Batch &b) {
+  const SplitJob job{v, nullptr, nullptr, b.in_stride, exps};
+  return launch_row_max_multi(&job, 1, stream, b.count, b.ws_stride);
 }
 
 // ---- shared: load one 32 rows x 32 k block, lane (r = lane&31, kh = lane>>5) gets its 16 k values ---
@@ -247,21 +279,15 @@ __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e,
 // kernel sits at 2 waves/SIMD, too few to hide HBM latency by occupancy alone (8192^2: 0.53 -> 0.31 ms).
 // Row-contiguous operands keep one block per wave at 3 waves/SIMD (prefetching there only costs registers).
 template <bool KCONTIG, bool PREFETCH = KCONTIG>
-__global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in, size_t rows, size_t K,
-                                                  size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
-                                                  int8_t *__restrict__ planes, double *__restrict__ max_exp,
-                                                  size_t RB, size_t KB, int strip, long long in_stride,
-                                                  size_t ws_stride) {
-  __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
-  in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
-  exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(exps) + (size_t)blockIdx.z * ws_stride);
-  planes += (size_t)blockIdx.z * ws_stride;
-  max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(max_exp) + (size_t)blockIdx.z * ws_stride);
+__device__ __forceinline__ void cut_body(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
+                                         const uint32_t *__restrict__ exps, int S, int L, int8_t *__restrict__ planes,
+                                         double *__restrict__ max_exp, size_t RB, size_t KB, int strip, size_t block,
+                                         double (*tiles)[32][33]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int CUT_STRIP = PREFETCH ? strip : 1;
   // strips along the contiguous axis: k-contiguous -> CUT_STRIP k-blocks of one row-block, else CUT_STRIP row-blocks
   const size_t strips_fast = ((KCONTIG ? KB : RB) + CUT_STRIP - 1) / CUT_STRIP;
-  const size_t gw = (size_t)blockIdx.x * 4 + wave;
+  const size_t gw = block * 4 + wave;
   if (gw >= strips_fast * (KCONTIG ? RB : KB)) return;
   const size_t slow = gw / strips_fast, fast0 = (gw % strips_fast) * CUT_STRIP;
   const size_t nfast = KCONTIG ? KB : RB;
@@ -300,13 +326,88 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
   }
 }
 
+// one operand view per launch: each layout gets its own register budget (k-contiguous: 2 waves/SIMD with the LDS
+// transpose and prefetch; row-contiguous: 3 waves/SIMD) -- the form for operands that are bandwidth bound
+template <bool KCONTIG, bool PREFETCH = KCONTIG>
+__global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in, size_t rows, size_t K,
+                                                  size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
+                                                  int8_t *__restrict__ planes, double *__restrict__ max_exp,
+                                                  size_t RB, size_t KB, int strip, long long in_stride,
+                                                  size_t ws_stride) {
+  __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
+  in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
+  exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(exps) + (size_t)blockIdx.z * ws_stride);
+  planes += (size_t)blockIdx.z * ws_stride;
+  max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(max_exp) + (size_t)blockIdx.z * ws_stride);
+  cut_body<KCONTIG, PREFETCH>(in, rows, K, sr, sk, exps, S, L, planes, max_exp, RB, KB, strip, blockIdx.x, tiles);
+}
+
+// up to 4 operand views per launch (see row_max_kernel): the form for small problems
+__global__ __launch_bounds__(256) void cut_multi_kernel(const SplitJobs jobs) {
+  __shared__ double tiles[4][32][33];
+  int ji = 0;
+  uint32_t blk = blockIdx.x;
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    if (ji + 1 < jobs.count && blk >= jobs.nblk[ji]) {
+      blk -= jobs.nblk[ji];
+      ji++;
+    }
+  SplitJob j = jobs.job[0];
+  uint32_t strip = jobs.nx[0];
+  if (ji == 1) j = jobs.job[1], strip = jobs.nx[1];
+  if (ji == 2) j = jobs.job[2], strip = jobs.nx[2];
+  if (ji == 3) j = jobs.job[3], strip = jobs.nx[3];
+  const size_t off = (size_t)blockIdx.z * jobs.ws_stride;
+  const double *in = j.v.in + (long long)blockIdx.z * j.in_stride;
+  const uint32_t *exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(j.exps) + off);
+  double *max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + off);
+  const size_t RB = (j.v.rows + TILE_ROWS - 1) / TILE_ROWS * (TILE_ROWS / FRAG_ROWS), KB = (j.v.K + FRAG_K - 1) / FRAG_K;
+  if (j.v.stride_k < j.v.stride_r)
+    cut_body<true, true>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp, RB,
+                         KB, (int)strip, blk, tiles);
+  else
+    cut_body<false, false>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp,
+                           RB, KB, 1, blk, tiles);
+}
+
+static int cut_strip_for(bool kcontig, size_t RB, size_t KB) {
+  // strip length: up to 4 blocks per wave as long as >= 2048 workgroups remain to fill the chip
+  return !kcontig ? 1 : (RB * KB >= 4 * 8192 ? 4 : (RB * KB >= 2 * 8192 ? 2 : 1));
+}
+
+hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch,
+                            size_t ws_stride) {
+  if (count < 1 || count > 4) return hipErrorInvalidValue;
+  SplitJobs jobs{};
+  jobs.count = count;
+  jobs.S = S;
+  jobs.L = L;
+  jobs.ws_stride = ws_stride;
+  uint64_t total = 0;
+  for (int i = 0; i < count; i++) {
+    const OperandView &v = job[i].v;
+    jobs.job[i] = job[i];
+    const size_t RB = row_blocks_padded(v.rows), KB = k_blocks(v.K);
+    const bool kc = v.stride_k < v.stride_r;
+    const int strip = cut_strip_for(kc, RB, KB);
+    const size_t strips = ((kc ? KB : RB) + strip - 1) / strip * (kc ? RB : KB);
+    jobs.nx[i] = (uint32_t)strip;
+    jobs.nblk[i] = (uint32_t)((strips + 3) / 4);
+    total += jobs.nblk[i];
+  }
+  if (total == 0 || batch == 0) return hipSuccess;
+  if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cut_multi_kernel, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+  return hipGetLastError();
+}
+
 hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, int8_t *planes,
                       double *max_exp, hipStream_t stream, const Batch &b) {
   const size_t RB = row_blocks_padded(v.rows), KB = k_blocks(v.K);
   if (RB * KB == 0 || b.count == 0) return hipSuccess;
   const bool kcontig = v.stride_k < v.stride_r;
-  // strip length: up to 4 blocks per wave as long as >= 2048 workgroups remain to fill the chip
-  const int strip = !kcontig ? 1 : (RB * KB >= 4 * 8192 ? 4 : (RB * KB >= 2 * 8192 ? 2 : 1));
+  const int strip = cut_strip_for(kcontig, RB, KB);
   const size_t strips = ((kcontig ? KB : RB) + strip - 1) / strip * (kcontig ? RB : KB);
   const dim3 grid((unsigned)((strips + 3) / 4), 1, b.count);
   if (kcontig)
@@ -403,8 +504,8 @@ __global__ __launch_bounds__(256) void split_fused_kernel(const SplitJobs jobs) 
   uint32_t rb = blockIdx.x;
 #pragma unroll
   for (int q = 0; q < 3; q++)
-    if (ji + 1 < jobs.count && rb >= jobs.rb_count[ji]) {
-      rb -= jobs.rb_count[ji];
+    if (ji + 1 < jobs.count && rb >= jobs.nblk[ji]) {
+      rb -= jobs.nblk[ji];
       ji++;
     }
   SplitJob j = jobs.job[0];
@@ -432,8 +533,8 @@ hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipS
   uint32_t total = 0;
   for (int i = 0; i < count; i++) {
     jobs.job[i] = job[i];
-    jobs.rb_count[i] = (uint32_t)row_blocks_padded(job[i].v.rows);
-    total += jobs.rb_count[i];
+    jobs.nblk[i] = (uint32_t)row_blocks_padded(job[i].v.rows);
+    total += jobs.nblk[i];
   }
   if (total == 0 || batch == 0) return hipSuccess;
   hipLaunchKernelGGL(split_fused_kernel, dim3(total, 1, batch), dim3(256), 0, stream, jobs);

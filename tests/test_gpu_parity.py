@@ -15,6 +15,18 @@ from tests.util import ColMajor, exp_rand, operand, uniform01, uniform_pm1, wide
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["multi_view_split", "banded_split", "one_pass_split"])
+def split_kernel(request, monkeypatch):
+    """every test runs with the three split implementations: one launch per pass for all operand views (what the
+    library does at these sizes), one launch per view walking row bands (what it does for operands larger than the
+    Infinity Cache; the band size is forced down so that these shapes have several bands), and the one-pass kernel"""
+    if request.param == "banded_split":
+        monkeypatch.setenv("OZIMMU_HIP_SPLIT_MULTI_BYTES", "0")
+        monkeypatch.setenv("OZIMMU_HIP_SPLIT_BAND_BYTES", "65536")
+    elif request.param == "one_pass_split":
+        monkeypatch.setenv("OZIMMU_HIP_SPLIT_ONE_PASS_BYTES", str(1 << 40))
+
 OPS = ["N", "T"]
 
 

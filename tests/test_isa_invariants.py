@@ -53,6 +53,50 @@ def test_throttle_scalar_load_is_not_touched_before_its_wait(asm):
     assert loads >= 8          # every prefetch-2 instantiation carries the probe
 
 
+def _kernels(text, substr):
+    """{name: body} of the kernels whose mangled name contains `substr`"""
+    out = {}
+    for m in re.finditer(r"^(_ZN5ozhip\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, flags=re.S | re.M):
+        if substr in m.group(1):
+            out[m.group(1)] = m.group(2)
+    return out
+
+
+def test_wide_kernel_register_placement_and_m0(asm):
+    """slice_gemm_w_kernel.h relies on three things the compiler does not promise:
+    * the accumulators stay where the inline-asm MFMAs pinned them: no v_accvgpr_* copies inside the k loop (the
+      builtin form produced hundreds, plus scratch);
+    * M0 is written only by the LDS-DMA statements and read by nothing else (it is not saved / restored);
+    * the LDS-DMA copies are invisible to the compiler's counters: fragment waits are COUNTED lgkmcnt(n > 0), not
+      lgkmcnt(0) drains (what the LDS-DMA builtin causes)."""
+    ks = _kernels(asm["slice_gemm.hip"], "slice_gemm_w_kernel")
+    assert len(ks) >= 12
+    for name, body in ks.items():
+        lines = body.split("\n")
+        # the software-pipelined k loop: from the first loop header to its back edge
+        start = next(i for i, l in enumerate(lines) if "Loop Header" in l)
+        loop = []
+        for l in lines[start:]:
+            loop.append(l)
+            if re.search(r"s_cbranch_scc\d .LBB\d+_\d+", l) and len(loop) > 200:
+                break
+        text = "\n".join(loop)
+        assert text.count("v_mfma_i32_32x32x32_i8") >= 30, name
+        assert "v_accvgpr" not in text, f"{name}: accumulator copies inside the k loop"
+        assert "scratch_" not in text, name
+        in_asm = False
+        for l in lines:
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif not in_asm and re.search(r"\bm0\b", l) and not l.strip().startswith(";"):
+                pytest.fail(f"{name}: compiler-generated use of m0: {l.strip()}")
+        counted = len(re.findall(r"s_waitcnt lgkmcnt\([1-9]\d*\)", text))
+        drains = len(re.findall(r"s_waitcnt lgkmcnt\(0\)", text))
+        assert counted >= 10 and drains <= 3, (name, counted, drains)
+
+
 def test_kernels_do_not_spill(asm):
     for src, text in asm.items():
         for m in re.finditer(r"\.private_segment_fixed_size: (\d+)", text):

@@ -1,0 +1,50 @@
+import torch, time, sys, os
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create()
+oz.set_cuda_stream(h, torch.cuda.current_stream())
+def bench(n, env):
+    for k, v in env.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    def call(): oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, "fp64_int8_9")
+    for _ in range(3): call()
+    torch.cuda.synchronize()
+    reps = 100 if n <= 2048 else 20
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps): call()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / reps)
+    return best
+def rocblas(n):
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    def call(): oz.native_dgemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.0, c, n)
+    for _ in range(3): call()
+    torch.cuda.synchronize()
+    reps = 100 if n <= 2048 else 20
+    t0 = time.perf_counter()
+    for _ in range(reps): call()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+for n in (1024, 1536, 2048, 2560, 3072, 4096, 6144, 8192):
+    r = rocblas(n)
+    line = f"n={n}: rocblas {r*1e6:8.1f} us ({2*n**3/r/1e12:5.1f} TF)"
+    for name, env in (("classic", dict(OZIMMU_HIP_GEMM_KERNEL="classic")),
+                      ("wide", dict(OZIMMU_HIP_GEMM_KERNEL="wide")),
+                      ("wide, split per view", dict(OZIMMU_HIP_GEMM_KERNEL="wide", OZIMMU_HIP_SPLIT_MULTI_BYTES="0")),
+                      ("wide, per view, 1 band", dict(OZIMMU_HIP_GEMM_KERNEL="wide", OZIMMU_HIP_SPLIT_MULTI_BYTES="0",
+                                                      OZIMMU_HIP_SPLIT_BAND_BYTES="0")),
+                      ("default", dict())):
+        for k_ in ("OZIMMU_HIP_GEMM_KERNEL", "OZIMMU_HIP_SPLIT_MULTI_BYTES", "OZIMMU_HIP_SPLIT_BAND_BYTES",
+                   "OZIMMU_HIP_SPLIT_ONE_PASS_BYTES"):
+            os.environ.pop(k_, None)
+        t = bench(n, env)
+        line += f" | {name} {t*1e6:8.1f} us ({2*n**3/t/1e12:5.1f} TF)"
+    print(line, flush=True)
+oz.destroy(h)

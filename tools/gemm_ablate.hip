@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "slice_gemm_w_kernel.h"
@@ -197,13 +198,45 @@ int main(int argc, char **argv) {
   { // cycle stamps of the wide kernel (VARW_TRACE): where a k-step spends its time
     uint32_t *tr;
     const size_t ntr = 32 * 4 * 8 * 8;
-    CK(hipMalloc(&tr, ntr * 4));
-    CK(hipMemset(tr, 0, ntr * 4));
+    const size_t nwg_max = 16384;
+    const size_t tr_bytes = 4096 * 8 + nwg_max * 3 * 8;
+    CK(hipMalloc(&tr, tr_bytes));
+    CK(hipMemset(tr, 0, tr_bytes));
     SliceGemmArgs b = a;
     b.acc = reinterpret_cast<double *>(tr);
-    run_w<S, 3, VARW_NA3 | VARW_TRACE>(b, st, e0, e1);
+    run_w<S, 3, VARW_NA3 | VARW_TRACE, 0, -1, 4, 6, true>(b, st, e0, e1);
     std::vector<uint32_t> h(ntr);
     CK(hipMemcpy(h.data(), tr, ntr * 4, hipMemcpyDeviceToHost));
+    { // per-CU timeline: when does each CU run dry, how long are the gaps between its workgroups
+      std::vector<unsigned long long> w(nwg_max * 3);
+      CK(hipMemcpy(w.data(), reinterpret_cast<unsigned long long *>(tr) + 4096, nwg_max * 24, hipMemcpyDeviceToHost));
+      std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> cu;
+      unsigned long long t_begin = ~0ull, t_end = 0;
+      size_t nwg = 0;
+      for (size_t i = 0; i < nwg_max; i++)
+        if (w[3 * i + 2]) {
+          cu[w[3 * i]].push_back({w[3 * i + 1], w[3 * i + 2]});
+          t_begin = std::min(t_begin, w[3 * i + 1]);
+          t_end = std::max(t_end, w[3 * i + 2]);
+          nwg++;
+        }
+      double busy = 0, gaps = 0, tail = 0, head = 0;
+      for (auto &kv : cu) {
+        auto &v = kv.second;
+        std::sort(v.begin(), v.end());
+        head += (double)(v.front().first - t_begin);
+        tail += (double)(t_end - v.back().second);
+        for (size_t i = 0; i < v.size(); i++) {
+          busy += (double)(v[i].second - v[i].first);
+          if (i) gaps += (double)(v[i].first - v[i - 1].second);
+        }
+      }
+      const double span = (double)(t_end - t_begin) * cu.size();
+      std::printf("wide timeline: %zu workgroups on %zu CUs, kernel span %.3f ms; CU time: busy %.2f %%, idle before first "
+                  "workgroup %.2f %%, gaps between workgroups %.2f %%, idle after last workgroup (tail) %.2f %%\n",
+                  nwg, cu.size(), (double)(t_end - t_begin) / 1e5, 100 * busy / span, 100 * head / span, 100 * gaps / span,
+                  100 * tail / span);
+    }
     auto d = [](uint32_t x, uint32_t y) { return (double)(uint32_t)(y - x); };
     double sum[8] = {0};
     int cnt = 0;
