@@ -318,6 +318,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
     g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
     g.acc_in = kb0 != 0;
     g.final = g.kb1 == g.KB;
+    g.qslot = 2u * (uint32_t)launches; // per-launch claim counters of the wide kernel (two per K chunk: S > 12)
     // C is written by the final launch(es) only (earlier passes go to the FP64 workspace); S > 12 splits the final
     // pass into two launches of which only the second writes C: a failed launch leaves C untouched
     if (!launch_gemm_checked(S, g, h->stream, launches)) return 3;
@@ -471,6 +472,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
       g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
       g.acc_in = kb0 != 0;
       g.final = g.kb1 == g.KB;
+      g.qslot = 2u * (uint32_t)launches;
       if (!launch_gemm_checked(S, g, h->stream, launches)) return 4;
     }
   }

@@ -28,7 +28,11 @@ struct SliceGemmArgs {
   double *acc; // [N][M] FP64 partial sums (multi-pass only)
   int acc_in;  // start the fma chain from acc instead of 0
   int final;   // 1: scale + alpha/beta -> C; 0: -> acc
-  uint32_t *phase; // 8 advisory words (one per XCD): k-block the XCD's workgroups are at; zeroed per call
+  uint32_t *phase; // 8 advisory words (one per XCD, 256 bytes apart): k-block the XCD's workgroups are at; zeroed per call
+  // wide kernel, persistent form: per-XCD claim counters {big tiles, small tiles} at queue[64 * xcd + {0, 1}], zeroed per
+  // call (they live in the phase lines: words 16 + 2 * qslot); nullptr: one tile per workgroup
+  uint32_t *queue;
+  uint32_t qslot; // set by the host pipeline: counter pair for this launch (a call may need several launches)
   uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
   int32_t *dump; // test hook: INT32 diagonal sums [S][N][M] (nullptr in production)
   int dump_only; // test hook: skip the FP64 epilogue

@@ -22,6 +22,7 @@
 // register the 32 lanes of a half-wave store 32 consecutive doubles of column-major C (256 B runs).
 //
 // Roofline: MFMA INT8 (dense 1024 MAC/clk/SIMD).  Algorithmic work per launch: P*2*M*N*K ops.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -83,7 +84,9 @@ static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
 
 // ---- wide kernel: one 4-wave workgroup per CU, (32*WA) x 128 tiles (slice_gemm_w_kernel.h) ------------------------
 // WA: as many blocks per wave as the 512-entry register file holds next to the B fragments, the ring and addressing;
-// NA: 3 A buffers (prefetch distance 2) when the LDS allows, else 2.
+// NA: 2 A buffers = prefetch distance 1.  Distance 2 (3 buffers) is never faster and up to 6 % slower (profiles/
+// r2_ablate: 17.66 vs 18.74 ms on the slowest box, equal on the fastest): a k-step of this kernel lasts ~2.8 us, enough
+// for a copy to land, and prefetching two steps ahead widens the k window the XCD's workgroups keep alive in L2.
 template <int S, int D0, int ND>
 struct WideCfg {
   static constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
@@ -94,7 +97,7 @@ struct WideCfg {
                             : (regs_ok(3) && lds(3, 2) <= LDS_MAX) ? 3
                             : (regs_ok(2) && lds(2, 2) <= LDS_MAX) ? 2
                                                                    : 0;
-  static constexpr int NA = (WA && lds(WA, 3) <= LDS_MAX) ? 3 : 2;
+  static constexpr int NA = 2;
   static constexpr bool ok = WA >= 2;
 };
 
@@ -143,6 +146,13 @@ static WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) {
     }
     if (n3 == 0) break;
   }
+  if (const char *e = getenv("OZIMMU_HIP_WIDE_SMALL_ROWS")) { // measurement override: rows of reduced-height tiles
+    const uint32_t n2 = std::min<uint32_t>((uint32_t)std::atoi(e), max_small);
+    const uint32_t covered = (uint32_t)(WA - 1) * n2;
+    best.n_small = n2;
+    best.n_big = covered >= rows32 ? 0 : (rows32 - covered + WA - 1) / WA;
+    best.makespan = simulate_rounds((uint64_t)best.n_big * tn, WA + OVH, (uint64_t)n2 * tn, WA - 1 + OVH, ncu);
+  }
   best.efficiency = (double)rows32 * tn / (best.makespan * ncu);
   return best;
 }
@@ -172,7 +182,20 @@ static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipSt
   a.rba = (uint32_t)row_blocks_padded(a.M);
   static std::atomic<uint64_t> attr_done{0};
   if (hipError_t e = allow_dynamic_lds(slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>, lds, attr_done)) return e;
-  const uint32_t nb = (a.tiles_m + a.tiles_m2) * a.tiles_n;
+  uint32_t nb = (a.tiles_m + a.tiles_m2) * a.tiles_n;
+  // persistent workgroups with per-XCD tile queues + stealing when there is a zeroed counter pair for this launch
+  // (single products only: the phase lines are per call) and more tiles than CUs; OZIMMU_HIP_WIDE_STATIC=1: A/B
+  a.queue = nullptr;
+  const uint32_t max_slots = 24; // words 16 .. 63 of a phase line
+  if (a.phase && a.batch <= 1 && a.qslot < max_slots && nb > (uint32_t)cu_count() &&
+      !(getenv("OZIMMU_HIP_WIDE_STATIC") && std::atoi(getenv("OZIMMU_HIP_WIDE_STATIC")))) {
+    a.queue = a.phase + 16 + 2 * a.qslot;
+    nb = (uint32_t)cu_count();
+    if (const char *e = getenv("OZIMMU_HIP_WIDE_GRID")) nb = std::max(1, std::atoi(e)); // tests: few workgroups, many tiles each
+  } else if (getenv("OZIMMU_HIP_WIDE_GRID") && a.phase && a.batch <= 1 && a.qslot < max_slots) {
+    a.queue = a.phase + 16 + 2 * a.qslot;
+    nb = std::min<uint32_t>(nb, (uint32_t)std::max(1, std::atoi(getenv("OZIMMU_HIP_WIDE_GRID"))));
+  }
   hipLaunchKernelGGL((slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>), dim3(nb, a.batch > 1 ? a.batch : 1), dim3(256), lds,
                      stream, a);
   return hipGetLastError();
@@ -212,6 +235,7 @@ static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     SliceGemmArgs a2 = a;
     a2.acc_in = 1;
+    a2.qslot = a.qslot + 1; // own claim counters (the host advances qslot by 2 per call of launch_slice_gemm)
     if (a2.dump) a2.dump += (size_t)ND1 * a.N * a.M;
     return launch_pass<S, ND1, ND2>(a2, stream);
   }

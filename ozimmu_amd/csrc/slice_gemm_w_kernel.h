@@ -48,6 +48,14 @@ __device__ __forceinline__ void mfma_vgpr(v16i &c, const v4i &b, const v4i &a) {
 // wait state after an M0 write, and the copy itself -- instruction slots between MFMAs are what a lone wave per SIMD
 // is short of.  M0 is compiler-reserved; nothing else in these kernels reads it (tests/test_isa_invariants.py checks
 // the ISA), so it is not saved / restored (-1.8 % kernel time).
+// a wave-uniform pointer, stated as such (inside the persistent tile loop hipcc's divergence analysis no longer proves
+// it and would hand the copies a VGPR pair; two v_readfirstlane per tile, outside the k loop)
+__device__ __forceinline__ const int8_t *uniform_ptr(const int8_t *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const int8_t *)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int IMM>
 __device__ __forceinline__ void glds16(const int8_t *sbase, uint32_t voff, uint32_t lds_a, uint32_t lds_b) {
   asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%c4"
@@ -111,7 +119,8 @@ constexpr int VARW_BAND16 = 32;    // measurement: 16 x 2
 
 // One output tile of (32*WA) x 128: rows start at A row-block rb0, columns at B row-block 4*tn.
 template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0_, int DMAE_, int TAIL_>
-__device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const uint32_t rb0, const uint32_t tn) {
+__device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const uint32_t rb0, const uint32_t tn,
+                                       const uint32_t xcd) {
   constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
   constexpr int NA = (VARW & VARW_NA3) ? 3 : 2;
   constexpr int PD = NA - 1;                       // prefetch distance in k-steps
@@ -144,10 +153,10 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
     const uint32_t a = q / SL, s = q - a * SL;
     uint32_t rb = rb0 + a;
     if (rb > rba_last) rb = rba_last;
-    a_src[t] = p.a_planes + rb * rb_stride + s * FRAG_BYTES + pass0;
+    a_src[t] = uniform_ptr(p.a_planes + rb * rb_stride + s * FRAG_BYTES + pass0);
     a_lds[t] = q * FRAG_BYTES;
   }
-  const int8_t *b_src = p.b_planes + (size_t)(4u * tn + wave) * rb_stride + pass0;
+  const int8_t *b_src = uniform_ptr(p.b_planes + (size_t)(4u * tn + wave) * rb_stride + pass0);
 
   // The copies are inline asm (glds16): hipcc counts an LDS-DMA builtin on BOTH vmcnt and lgkmcnt, after which every
   // wait it places in front of a fragment's first use is lgkmcnt(0) -- draining the ring read issued just before it
@@ -204,7 +213,7 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
 
   // ---- circular K with the per-XCD phase hint (slice_gemm_kernel.h) ----------------------------------------------
   const uint32_t nk = p.kb1 - p.kb0;
-  uint32_t *phase = p.phase ? p.phase + 64u * (blockIdx.x & 7u) : nullptr;
+  uint32_t *phase = p.phase ? p.phase + 64u * xcd : nullptr;
   uint32_t koff = 0;
   if (phase && nk > 1) {
     if (threadIdx.x == 0)
@@ -233,16 +242,18 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   // ---- schedule of one k-step (compile time) ---------------------------------------------------------------------
   // SC lists the MFMA slots of a k-step: block a outermost, A slice i ascending, B slice j descending; a "group" is the
   // run of slots that share one A fragment (a, i).  Events are attached to slots:
-  //   * first slot of group g: read the A fragment of group g+R-1 into ring slot (g+R-1) % R (the slot of group g-1);
-  //     the group sequence is padded with empty groups to a multiple of R (NGP) so that the ring position of a group
-  //     is the same in every k-step and the prefetch runs across the step boundary into the next stage's buffer;
+  //   * the fragment of group 0 has its own register af0, (re)loaded right behind the barrier for the next k-step: the
+  //     step's first MFMA must not wait for an LDS read issued at the end of the previous step;
+  //   * groups 1.. go through a ring of R registers: first slot of group g: read the fragment of group g+R-1 into the
+  //     ring slot that group g-1 just released.  Ring positions are padded to a multiple of R per k-step (NRP) so that
+  //     a group's slot is the same in every step and the prefetch runs across the step boundary into the next buffer;
   //   * slots DMA0, DMA0+DMAE, ...: one LDS-DMA copy of the stage PD steps ahead (A share first, then the private B);
   //   * slot NS-TAIL ("X"): wait for the own copies of the NEXT stage, barrier, then refresh bf[JT..] from it; the TAIL
   //     remaining MFMAs of this step use bf[0..JT-1] only and cover the barrier and the LDS latency; bf[0..JT-1] are
   //     refreshed behind the last MFMA and are needed last in the next step's first group (j descending).
 #define SC (kWSched<S, D0, ND, WA>) /* namespace-scope constexpr object: usable inside the lambdas below */
   constexpr int NS = SC.ns;
-  constexpr int NGP = (NG + R - 1) / R * R;
+  constexpr int NRP = (NG - 1 + R - 1) / R * R; // ring positions per k-step: group g >= 1 has position g - 1
   constexpr int TAIL = TAIL_ < NS ? TAIL_ : NS - 1;
   constexpr int XS = NS - TAIL;
   constexpr int DMA0 = DMA0_ >= 0 ? DMA0_ : SC.gfirst[1 < NG ? 1 : 0]; // default: behind the first group
@@ -250,8 +261,11 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   constexpr int DMAE = DMAE_ < DMAE_FIT ? DMAE_ : (DMAE_FIT > 1 ? DMAE_FIT : 1);
   constexpr int JT = SC.max_j_from(XS) + 1; // B slices still needed after X
   static_assert(SC.ng == NG, "empty (a, i) groups are not supported by the ring arithmetic");
-  static_assert(NGP - (R - 1) >= NG || SC.gfirst[NGP - (R - 1) < NG ? NGP - (R - 1) : 0] >= XS,
-                "the first fragment read of the next stage must come after the barrier");
+  // next-step group q (1 <= q < R) is read at the first slot of group NRP + q - R + 1 if that group exists (else
+  // behind the last slot): never before the barrier
+  static_assert(NRP + 2 - R > NG - 1 || SC.gfirst[NRP + 2 - R <= NG - 1 && NRP + 2 - R >= 0 ? NRP + 2 - R : 0] >= XS,
+                "the first ring read of the next stage must come after the barrier");
+  static_assert(NG >= 2, "at least two groups per k-step");
   static_assert(DMA0 + (NDMA - 1) * DMAE < XS, "every copy of a stage is issued before the barrier slot");
   static_assert(PD == 1 || DMA0 + NQA * DMAE >= SC.last_use_of_j_below(JT, 0) + 1,
                 "distance 2: the B copies overwrite the buffer bf[0..JT-1] were read from at the end of the last step");
@@ -259,10 +273,14 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   const char *la0 = smem + lane * 16;
   const char *lb0 = smem + OFF_B + wave * (SL * FRAG_BYTES) + lane * 16;
   int abuf = 0, bbuf = 0; // buffers of the stage being computed
-  v4i bf[SL], af[R];
-  auto read_a = [&](auto gc, const char *la) { // A fragment of group g -> ring
+  v4i bf[SL], af[R], af0;
+  auto read_a = [&](auto gc, const char *la) { // A fragment of group g -> af0 (g == 0) or ring slot (g - 1) % R
     constexpr int g = decltype(gc)::value;
-    af[g % R] = *(const v4i *)(la + (SC.g_a[g] * SL + SC.g_i[g]) * FRAG_BYTES);
+    const v4i f = *(const v4i *)(la + (SC.g_a[g] * SL + SC.g_i[g]) * FRAG_BYTES);
+    if constexpr (g == 0)
+      af0 = f;
+    else
+      af[(g - 1) % R] = f;
   };
 
   // ---- prologue: stages 0 .. PD-1 in flight, stage 0 landed, its B fragments and first A fragments in registers --
@@ -287,7 +305,7 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < SL; j++) bf[j] = *(const v4i *)(lb0 + j * FRAG_BYTES);
-    static_for<(R - 1 < NG ? R - 1 : NG)>([&](auto gc) { read_a(gc, la0); });
+    static_for<(R < NG ? R : NG)>([&](auto gc) { read_a(gc, la0); }); // group 0 and the ring's first R - 1 entries
   }
   asm volatile("s_nop 7" ::: "memory"); // zero-fill (VALU / v_accvgpr_write) -> first MFMA reading it as C
 
@@ -334,15 +352,16 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
         if constexpr (TRACE) ts[3] = stamp();
         if constexpr (STAG > 0) // de-phase the 4 lockstep waves so that their copies do not queue in the TA
           for (int q = 0; q < wave; q++) asm volatile("s_nop %0" ::"n"(STAG - 1));
+        read_a(std::integral_constant<int, 0>{}, la_n); // next step's first fragment (group 0 of this step is long done)
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (SC.gfirst[g] == s && !MFMA_ONLY) {
-        constexpr int gn = g + R - 1;
+      if constexpr (SC.gfirst[g] == s && g >= 1 && !MFMA_ONLY) {
+        constexpr int gn = g + R - 1; // ring position gn - 1 = (g - 1) + R - 1
         if constexpr (gn < NG) {
           read_a(std::integral_constant<int, gn>{}, la);
           __builtin_amdgcn_sched_barrier(0);
-        } else if constexpr (gn >= NGP && NX) {
-          read_a(std::integral_constant<int, gn - NGP>{}, la_n);
+        } else if constexpr (gn - 1 >= NRP && NX) {
+          read_a(std::integral_constant<int, gn - NRP>{}, la_n);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -356,7 +375,7 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
       if constexpr (MFMA_ONLY)
         mfma(std::integral_constant<int, a * ND + i + j - D0>{}, cf[j], cf[i]);
       else
-        mfma(std::integral_constant<int, a * ND + i + j - D0>{}, bf[j], af[g % R]);
+        mfma(std::integral_constant<int, a * ND + i + j - D0>{}, bf[j], g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       // behind the barrier the matrix pipe gets its next MFMA first; the refresh of bf[JT..] from the next stage (and
       // the phase hint) follow in the shadow of the TAIL MFMAs, RPT reads per slot
       if constexpr (s >= XS && NX && !MFMA_ONLY) {
@@ -376,10 +395,10 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
     if constexpr (NX && !MFMA_ONLY) {
 #pragma unroll
       for (int j = 0; j < JT; j++) bf[j] = *(const v4i *)(lb_n + j * FRAG_BYTES);
-      // next-stage A fragments whose trigger group is one of the empty padding groups
+      // next-stage ring fragments whose trigger group does not exist (padding positions)
       static_for<R - 1>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        if constexpr (NGP + q - (R - 1) >= NG && q < NG) read_a(qc, la_n);
+        constexpr int q = decltype(qc)::value + 1; // next-step groups 1 .. R-1
+        if constexpr (NRP + q - R + 1 > NG - 1 && q < NG) read_a(std::integral_constant<int, q>{}, la_n);
       });
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -427,11 +446,17 @@ __device__ __forceinline__ void band_order(uint32_t lid, uint32_t rows, uint32_t
   r = band * BH + rem % h;
 }
 
-// Grid = tiles_m x tiles_n "big" tiles of WA blocks + tiles_m2 x tiles_n "small" tiles of WA-1 blocks below them.  The
+// Tiles: tiles_m x tiles_n "big" tiles of WA blocks + tiles_m2 x tiles_n "small" tiles of WA-1 blocks below them.  The
 // mix lets the host fit the row count and the number of CU rounds (8192 rows = 80 x 96 + 8 x 64: 20 + 2 full rounds
-// on 256 CUs instead of 21.5 -> 22 with 96-row tiles only).  Every XCD gets a contiguous run of each region, big
-// tiles first; the extras of the small region start at the XCD where the big region's extras stop, which makes the
-// per-XCD totals equal to what the round-robin dispatch hands each XCD.
+// on 256 CUs instead of 21.5 -> 22 with 96-row tiles only).  Every XCD owns a contiguous run of each region (L2 panel
+// sharing), big tiles first.
+//
+// p.queue == nullptr: one tile per workgroup, grid = number of tiles; the extras of the small region start at the XCD
+// where the big region's extras stop, so the per-XCD totals equal what the round-robin dispatch hands each XCD.
+// p.queue != nullptr: PERSISTENT workgroups (grid = one per CU) claim tiles from their XCD's run through two counters per
+// XCD and, when it is exhausted, from the other XCDs' runs.  The XCDs do not run at the same speed (measured: the odd
+// ones finish an 8192^3 launch up to 0.9 ms after the even ones, profiles/r2_ablate/*timeline*); a static partition
+// leaves that as an idle tail on 3 % of the CU time.
 template <int S, int D0, int ND, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL_ = 6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void slice_gemm_w_kernel(
     const SliceGemmArgs p_in) {
@@ -440,18 +465,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   unsigned long long wg_t0 = 0;
   if constexpr ((VARW & VARW_TRACE) != 0) wg_t0 = wall_clock64();
   const uint32_t nbig = p.tiles_m * p.tiles_n, nsmall = p.tiles_m2 * p.tiles_n;
-  const uint32_t xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-  const uint32_t nbig_x = (nbig >> 3) + (xcd < (nbig & 7u) ? 1u : 0u);
-  uint32_t r, c;
   constexpr uint32_t BH = (VARW & VARW_BAND4) ? 4u : (VARW & VARW_BAND16) ? 16u : 8u;
-  if (idx < nbig_x) {
-    band_order<BH>(xcd_run_start(xcd, nbig) + idx, p.tiles_m, p.tiles_n, r, c);
-    w_tile<S, D0, ND, WA, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * r, c);
-  } else {
-    if constexpr (WA > 1) {
-      band_order<BH>(xcd_run_start((xcd - (nbig & 7u)) & 7u, nsmall) + (idx - nbig_x), p.tiles_m2, p.tiles_n, r, c);
-      w_tile<S, D0, ND, WA - 1, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * p.tiles_m + (WA - 1) * r, c);
+  uint32_t xcd = blockIdx.x & 7u;
+  if (p.queue) { // the XCD this workgroup really runs on (placement is not architecturally tied to blockIdx)
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    xcd = __builtin_amdgcn_readfirstlane(x & 7u);
+  }
+  const uint32_t small_shift = nbig & 7u; // the small region's runs are rotated by the big region's remainder
+  for (;;) {
+    uint32_t kind = 0, lid = 0; // 1: big tile `lid` of its region, 2: small tile, 0: nothing left
+    if (!p.queue) {
+      const uint32_t idx = blockIdx.x >> 3;
+      const uint32_t nbig_x = (nbig >> 3) + (xcd < (nbig & 7u) ? 1u : 0u);
+      if (idx < nbig_x) {
+        kind = 1;
+        lid = xcd_run_start(xcd, nbig) + idx;
+      } else {
+        kind = 2;
+        lid = xcd_run_start((xcd - small_shift) & 7u, nsmall) + (idx - nbig_x);
+      }
+    } else {
+      __syncthreads(); // the previous tile's LDS reads are done
+      if (threadIdx.x == 0) {
+        uint32_t k = 0, l = 0;
+        for (uint32_t region = 1; region <= 2 && !k; region++) {
+          const uint32_t n = region == 1 ? nbig : nsmall;
+          for (uint32_t v = 0; v < 8 && !k; v++) { // own run first, then the neighbours'
+            const uint32_t x = (xcd + v) & 7u, xr = region == 1 ? x : (x - small_shift) & 7u;
+            const uint32_t len = (n >> 3) + (xr < (n & 7u) ? 1u : 0u);
+            uint32_t *cnt = p.queue + 64u * x + (region - 1);
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+            const uint32_t t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < len) {
+              k = region;
+              l = xcd_run_start(xr, n) + t;
+            }
+          }
+        }
+        reinterpret_cast<volatile uint32_t *>(smem)[0] = k;
+        reinterpret_cast<volatile uint32_t *>(smem)[1] = l;
+      }
+      __syncthreads();
+      kind = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile uint32_t *>(smem)[0]);
+      lid = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile uint32_t *>(smem)[1]);
+      __syncthreads(); // smem is staging space again
+      if (!kind) break;
     }
+    uint32_t r, c;
+    if (kind == 1) {
+      band_order<BH>(lid, p.tiles_m, p.tiles_n, r, c);
+      r = __builtin_amdgcn_readfirstlane(r); // wave-uniform by construction; say so (the copies take SGPR operands)
+      c = __builtin_amdgcn_readfirstlane(c);
+      w_tile<S, D0, ND, WA, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * r, c, xcd);
+    } else {
+      if constexpr (WA > 1) {
+        band_order<BH>(lid, p.tiles_m2, p.tiles_n, r, c);
+        r = __builtin_amdgcn_readfirstlane(r);
+        c = __builtin_amdgcn_readfirstlane(c);
+        w_tile<S, D0, ND, WA - 1, VARW, STAG, DMA0, DMAE, TAIL_>(p, smem, WA * p.tiles_m + (WA - 1) * r, c, xcd);
+      }
+    }
+    if (!p.queue) break;
   }
   if constexpr ((VARW & VARW_TRACE) != 0) { // per-workgroup placement and wall-clock span (100 MHz), after the step stamps
     if (threadIdx.x == 0) {

@@ -64,6 +64,28 @@ def test_wide_gemm_bit_exact_vs_oracle(oz, op_a, op_b, m, n, k, S):
     assert np.isnan(c.buf[:, m:]).all()  # ld padding untouched
 
 
+@pytest.mark.parametrize("grid", [1, 3, 7])
+@pytest.mark.parametrize("m,n,k,S", [(700, 520, 96, 9), (333, 900, 70, 6), (500, 300, 20000, 9), (260, 390, 64, 14)])
+def test_wide_persistent_workgroups_claim_many_tiles(oz, monkeypatch, grid, m, n, k, S):
+    """the persistent form of the kernel (per-XCD tile queues + stealing, what large problems run): forced down to a
+    handful of workgroups so that each one walks many tiles of both heights, re-using its LDS and registers; K chunks
+    and the two diagonal passes use separate claim counters"""
+    m_, h = oz
+    monkeypatch.setenv("OZIMMU_HIP_WIDE_GRID", str(grid))
+    rng = np.random.default_rng(m + n + k + S + grid)
+    a = operand("T", m, k, rng, pad=1)
+    b = operand("N", k, n, rng)
+    c = ColMajor(m, n, fill=uniform_pm1, rng=rng)
+    c_ref = ColMajor(m, n)
+    c_ref.buf[...] = c.buf
+    assert m_.gemm(h, "T", "N", m, n, k, 1.5, a.dev, a.ld, b.dev, b.ld, -0.5, c.dev, c.ld, f"fp64_int8_{S}") == 0
+    _sync()
+    kchunk = (2147483647 // (S * 127 * 127)) // 32 * 32
+    assert O.gemm("T", "N", m, n, k, 1.5, a.view, b.view, -0.5, c_ref.view, S, O.ORDER_DIAGONAL,
+                  kchunk=kchunk if k > kchunk else 0) == 0
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
 @pytest.mark.parametrize("alpha,beta", [(-2.5, 0.0), (1.0, 1.0), (0.75, -1.25)])
 def test_wide_gemm_alpha_beta(oz, alpha, beta):
     m_, h = oz

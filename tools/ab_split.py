@@ -1,0 +1,27 @@
+"""A/B of the split implementations at one size (environment switches are read per call)."""
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+def call(): assert oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, "fp64_int8_9") == 0
+variants = {"two-pass (default)": {}, "one-pass": {"OZIMMU_HIP_SPLIT_ONE_PASS_BYTES": str(1 << 40)},
+            "two-pass multi-view": {"OZIMMU_HIP_SPLIT_MULTI_BYTES": str(1 << 40)},
+            "two-pass 64 MiB bands": {"OZIMMU_HIP_SPLIT_BAND_BYTES": str(64 << 20)}}
+res = {}
+keys = ["OZIMMU_HIP_SPLIT_ONE_PASS_BYTES", "OZIMMU_HIP_SPLIT_MULTI_BYTES", "OZIMMU_HIP_SPLIT_BAND_BYTES"]
+oz.enable_profiling(h)
+for r in range(3):
+    for name, env in variants.items():
+        for k in keys: os.environ.pop(k, None)
+        os.environ.update(env)
+        call(); torch.cuda.synchronize()
+        st = []
+        for _ in range(4):
+            call(); x = oz.last_stage_ms(h); st.append(x["split_A"] + x["split_B"])
+        res.setdefault(name, []).append(sum(st) / len(st))
+for name, v in res.items():
+    v = sorted(v); print(f"n={n} split {name}: {v[len(v)//2]:.3f} ms")

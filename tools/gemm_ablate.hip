@@ -68,7 +68,7 @@ static float run_throttled(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e
 }
 
 // wide kernel (one 4-wave workgroup per CU, WA blocks per wave)
-template <int S, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL = 6, bool MIX = false>
+template <int S, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL = 6, bool MIX = false, bool DYN = false>
 static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   constexpr int NA = (VARW & VARW_NA3) ? 3 : 2;
   constexpr size_t lds = (size_t)(NA * WA + 2 * 4) * S * FRAG_BYTES;
@@ -95,8 +95,14 @@ static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEv
     done = true;
   }
   CK(hipMemsetAsync(a.phase, 0, 8 * 256, st));
+  uint32_t grid = (a.tiles_m + a.tiles_m2) * a.tiles_n;
+  a.queue = nullptr;
+  if (DYN) {
+    a.queue = a.phase + 16;
+    grid = 256;
+  }
   CK(hipEventRecord(e0, st));
-  hipLaunchKernelGGL((slice_gemm_w_kernel<S, 0, S, WA, VARW, STAG, DMA0, DMAE, TAIL>), dim3((a.tiles_m + a.tiles_m2) * a.tiles_n), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((slice_gemm_w_kernel<S, 0, S, WA, VARW, STAG, DMA0, DMAE, TAIL>), dim3(grid), dim3(256), lds, st, a);
   CK(hipEventRecord(e1, st));
   CK(hipEventSynchronize(e1));
   CK(hipGetLastError());
@@ -164,11 +170,13 @@ int main(int argc, char **argv) {
       {"shipped 64x64 + throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
       {"wide 96x128 pd2", run_w<S, 3, VARW_NA3>, false, {}},
       {"wide 96x128 pd2 mixed heights", run_w<S, 3, VARW_NA3, 0, -1, 4, 6, true>, false, {}},
-            {"wide 96x128 pd2 band 4x8", run_w<S, 3, VARW_NA3 | VARW_BAND4>, false, {}},
-      {"wide 96x128 pd2 band 16x2", run_w<S, 3, VARW_NA3 | VARW_BAND16>, false, {}},
-      {"wide 96x128 pd2 tail 3", run_w<S, 3, VARW_NA3, 0, -1, 4, 3>, false, {}},
-      {"wide 96x128 pd2 dma0 1", run_w<S, 3, VARW_NA3, 0, 1, 4>, false, {}},
+            {"wide 96x128 pd1 band 4x8 mixed", run_w<S, 3, VARW_BAND4, 0, -1, 4, 6, true>, false, {}},
       {"wide 96x128 pd1", run_w<S, 3, 0>, false, {}},
+      {"wide 96x128 pd1 mixed heights", run_w<S, 3, 0, 0, -1, 4, 6, true>, false, {}},
+      {"wide 96x128 pd1 mixed persistent+steal", run_w<S, 3, 0, 0, -1, 4, 6, true, true>, false, {}},
+      {"wide 96x128 pd1 persistent+steal", run_w<S, 3, 0, 0, -1, 4, 6, false, true>, false, {}},
+      {"wide 96x128 pd1 mixed dma every 6", run_w<S, 3, 0, 0, -1, 6, 6, true>, false, {}},
+      {"wide 96x128 pd1 mixed tail 10", run_w<S, 3, 0, 0, -1, 4, 10, true>, false, {}},
       {"wide 96x128 no-global", run_w<S, 3, VARW_NA3 | VARW_NO_GLOBAL>, false, {}},
       {"wide 96x128 mfma-only rand", run_w<S, 3, VARW_NA3 | VARW_MFMA_ONLY>, false, {}},
       {"64x64 mfma-only random regs", run<S, VAR_MFMA_ONLY | VAR_RAND_REGS>, false, {}},
@@ -188,7 +196,7 @@ int main(int argc, char **argv) {
       if (which == 1) run_w<S, 3, VARW_NA3>(a, st, e0, e1);
       if (which == 2) run_w<S, 3, 0>(a, st, e0, e1);
       if (which == 3) run_w<S, 3, VARW_NA3, 0, -1, 4, 6, true>(a, st, e0, e1);
-      if (which == 4) run_w<S, 3, VARW_NA3>(a, st, e0, e1);
+      if (which == 4) run_w<S, 3, 0, 0, -1, 4, 6, true, true>(a, st, e0, e1);
       CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
       size_t bad = 0;
       for (size_t i = 0; i < M * N; i++) bad += c0[i] != c1[i];
@@ -204,7 +212,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(tr, 0, tr_bytes));
     SliceGemmArgs b = a;
     b.acc = reinterpret_cast<double *>(tr);
-    run_w<S, 3, VARW_NA3 | VARW_TRACE, 0, -1, 4, 6, true>(b, st, e0, e1);
+    run_w<S, 3, VARW_TRACE, 0, -1, 4, 6, true, true>(b, st, e0, e1);
     std::vector<uint32_t> h(ntr);
     CK(hipMemcpy(h.data(), tr, ntr * 4, hipMemcpyDeviceToHost));
     { // per-CU timeline: when does each CU run dry, how long are the gaps between its workgroups
@@ -230,6 +238,19 @@ int main(int argc, char **argv) {
           busy += (double)(v[i].second - v[i].first);
           if (i) gaps += (double)(v[i].first - v[i - 1].second);
         }
+      }
+      { // does the tail come from whole XCDs finishing early (static partition of the grid) or from single CUs?
+        std::map<unsigned, unsigned long long> xcd_end, xcd_first_idle;
+        for (auto &kv : cu) {
+          const unsigned x = (unsigned)(kv.first >> 32);
+          xcd_end[x] = std::max(xcd_end[x], kv.second.back().second);
+          if (!xcd_first_idle.count(x)) xcd_first_idle[x] = kv.second.back().second;
+          xcd_first_idle[x] = std::min(xcd_first_idle[x], kv.second.back().second);
+        }
+        std::printf("wide timeline per XCD (ms before kernel end: last CU done / first CU idle):");
+        for (auto &kv : xcd_end)
+          std::printf("  x%u %.3f/%.3f", kv.first, (double)(t_end - kv.second) / 1e5, (double)(t_end - xcd_first_idle[kv.first]) / 1e5);
+        std::printf("\n");
       }
       const double span = (double)(t_end - t_begin) * cu.size();
       std::printf("wide timeline: %zu workgroups on %zu CUs, kernel span %.3f ms; CU time: busy %.2f %%, idle before first "
