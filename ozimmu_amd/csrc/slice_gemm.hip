@@ -157,9 +157,9 @@ static WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) {
   return best;
 }
 
-// The wide kernel wins as soon as its tiles occupy half of the CUs (measured, fp64_int8_9 square sizes, tools/
+// The wide kernel wins once its tiles occupy about 3/4 of the CUs (measured, fp64_int8_9 square sizes, tools/
 // bench_kernel_choice.py: 1536^3 = 192 tiles: 177 vs 211 us; 2048^3 339 vs 347; 3072^3 1006 vs 1124; 8192^3 16.9 vs
-// 19.5 ms; at 1024^3 its 88 tiles lose to the classic kernel's 256 of 64x64: 88 vs 77 us).
+// 19.5 ms; at 1024^3 its 128 tiles of 64x128 lose to the classic kernel's 256 of 64x64: 92 vs 76 us).
 // OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements, parity tests of both kernels on small shapes).
 static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu) {
   if (const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL")) {
@@ -167,7 +167,7 @@ static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu) {
     if (!std::strcmp(e, "classic")) return false;
   }
   const uint64_t wgs = (uint64_t)(pl.n_big + pl.n_small) * tn;
-  return 2 * wgs >= (uint64_t)ncu;
+  return 10 * wgs >= 7 * (uint64_t)ncu;
 }
 
 template <int S, int D0, int ND>
