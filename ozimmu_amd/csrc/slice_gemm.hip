@@ -205,13 +205,17 @@ static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipSt
 // chip, else the classic one
 template <int S, int D0, int ND, int FORCE_WM = 0>
 static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
-  if constexpr (WideCfg<S, D0, ND>::ok) {
+  // S <= 4: few MFMAs per staged byte even on 128x128 tiles; the classic 8-wave 128x64 kernel measures faster
+  // (4096^3: S=3 241 vs 214, S=4 174 vs 168 TFLOP/s; from S=5 on the wide kernel leads by 6-13 %)
+  constexpr bool wide_pays = ND >= 5 || D0 > 0;
+  if (WideCfg<S, D0, ND>::ok && (wide_pays || getenv("OZIMMU_HIP_GEMM_KERNEL"))) {
     const int ncu = cu_count();
     // a strided batch fills the chip with all its matrices: plan one matrix on the CUs it gets on average
     const uint32_t nbatch = a.batch > 1 ? a.batch : 1;
     const int ncu_eff = (int)(ncu / nbatch) > 0 ? (int)(ncu / nbatch) : 1;
     const WidePlan pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu_eff);
-    if (prefer_wide(pl, (a.N + 127) / 128, ncu_eff)) return launch_wide<S, D0, ND>(a, pl, stream);
+    if constexpr (WideCfg<S, D0, ND>::ok)
+      if (prefer_wide(pl, (a.N + 127) / 128, ncu_eff)) return launch_wide<S, D0, ND>(a, pl, stream);
   }
   return launch_one<S, D0, ND, FORCE_WM>(a, stream);
 }

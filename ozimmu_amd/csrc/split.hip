@@ -22,6 +22,8 @@
 // 16 + S).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "layout.h"
 
@@ -248,18 +250,35 @@ __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e,
     if (bq >> 63) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
   }
 
-  const unsigned long long mask = (1ull << L) - 1ull;
+  // Slice s = bits [p, p + L) of the 128-bit value, p = 128 - (s + 1) * L >= 2.  The kernel is VALU bound (rocprofv3:
+  // 1 770 VALU instructions per block in the first version, mostly 64-bit shifts at a fraction of the 32-bit rate),
+  // so the field extraction works on the four 32-bit words of (hi:lo): p is wave-uniform, the word index selects one of
+  // four unrolled bodies with a scalar branch, and a field costs one v_bfe_u32 (inside a word) or v_alignbit_b32 +
+  // v_and (across two words), plus one v_lshl_or_b32 to place its byte.
+  const unsigned mask = (1u << L) - 1u;
+  auto word = [&](int q, int i) -> unsigned { // word i (0 = least significant) of element q's 128-bit value
+    return i >= 4 ? 0u : i == 3 ? (unsigned)(hi[q] >> 32) : i == 2 ? (unsigned)hi[q] : i == 1 ? (unsigned)(lo[q] >> 32) : (unsigned)lo[q];
+  };
   for (int s = 0; s < S; s++) {
-    const int p = 128 - (s + 1) * L; // low bit of slice s inside (hi:lo); p >= 2 since S*L <= 126
+    const int p = 128 - (s + 1) * L;
+    const int wi = p >> 5, r = p & 31;
     unsigned w[4] = {0, 0, 0, 0};
+    auto extract = [&](auto wic) {
+      constexpr int WI = decltype(wic)::value;
+      if (r + L <= 32) {
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      unsigned long long x;
-      if (p >= 64)
-        x = hi[q] >> (p - 64);
-      else
-        x = (lo[q] >> p) | (hi[q] << (64 - p));
-      w[q >> 2] |= (unsigned)(x & mask) << (8 * (q & 3));
+        for (int q = 0; q < 16; q++) w[q >> 2] |= ((word(q, WI) >> r) & mask) << (8 * (q & 3));
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          w[q >> 2] |= (__builtin_amdgcn_alignbit(word(q, WI + 1), word(q, WI), (unsigned)r) & mask) << (8 * (q & 3));
+      }
+    };
+    switch (wi) { // wave-uniform
+      case 3: extract(std::integral_constant<int, 3>{}); break;
+      case 2: extract(std::integral_constant<int, 2>{}); break;
+      case 1: extract(std::integral_constant<int, 1>{}); break;
+      default: extract(std::integral_constant<int, 0>{}); break;
     }
     uint4 o;
     unsigned *op = &o.x;

@@ -1,0 +1,41 @@
+"""Strided batches: one set of launches for the whole batch (round 2) vs the reference's per-matrix loop (round 1's
+form, OZIMMU_HIP_BATCH_LOOP=1), through the direct API and through LD_PRELOAD + torch.bmm."""
+import os, subprocess, sys, textwrap, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1 and sys.argv[1] == "bmm":
+    import torch
+    b, n = 8, 1024
+    x = torch.rand(b, n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    y = torch.rand(b, n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    for _ in range(3): torch.bmm(x, y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): torch.bmm(x, y)
+    torch.cuda.synchronize()
+    print(f"{(time.perf_counter() - t0) / 20 * 1e6:.1f}")
+    sys.exit(0)
+import torch
+import ozimmu_amd as oz
+h = oz.create(); st = torch.cuda.current_stream(); oz.set_cuda_stream(h, st)
+for (b, n) in ((8, 1024), (32, 1024), (8, 2048), (64, 512)):
+    x = torch.rand(b, n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    y = torch.rand(b, n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(b, n, n, dtype=torch.float64, device="cuda")
+    res = {}
+    for name, env in (("loop", "1"), ("batched", None)):
+        if env: os.environ["OZIMMU_HIP_BATCH_LOOP"] = env
+        else: os.environ.pop("OZIMMU_HIP_BATCH_LOOP", None)
+        def call(): assert oz.gemm_strided_batched(h, st, "N", "N", n, n, n, 1.0, x, n, n * n, y, n, n * n, 0.0, c, n, n * n, b, "fp64_int8_9") == 0
+        for _ in range(3): call()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): call()
+        torch.cuda.synchronize(); res[name] = (time.perf_counter() - t0) / 20
+    print(f"batch {b} x {n}^3 fp64_int8_9: loop {res['loop']*1e6:8.1f} us ({2*b*n**3/res['loop']/1e12:5.1f} TF)   one launch set {res['batched']*1e6:8.1f} us "
+          f"({2*b*n**3/res['batched']/1e12:5.1f} TF)   x{res['loop']/res['batched']:.2f}", flush=True)
+oz.destroy(h)
+lib = os.path.join(ROOT, "ozimmu_amd", "libozimmu_hip.so")
+for name, extra in (("native rocBLAS", {}), ("preload, per-matrix loop", dict(LD_PRELOAD=lib, OZIMMU_COMPUTE_MODE="fp64_int8_9", OZIMMU_HIP_BATCH_LOOP="1")),
+                    ("preload, one launch set", dict(LD_PRELOAD=lib, OZIMMU_COMPUTE_MODE="fp64_int8_9"))):
+    e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}; e.update(extra)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "bmm"], env=e, capture_output=True, text=True).stdout.strip().splitlines()
+    print(f"torch.bmm 8 x 1024^3 float64, {name}: {out[-1] if out else '?'} us")
