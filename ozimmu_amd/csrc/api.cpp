@@ -973,6 +973,7 @@ int ozimmu_hip_diagonal_sums(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
                              size_t n, size_t k, const double *a, size_t lda, const double *b, size_t ldb,
                              unsigned num_split, int32_t *out) {
   if (!h || !out || num_split < 3 || num_split > 18 || m == 0 || n == 0 || k == 0) return 1;
+  if (m >= ((size_t)1 << 31) || n >= ((size_t)1 << 31) || bits_for_k(k) == 0) return 1; // 32-bit row / column indices
   if (check_gemm_shape(op_A, m, k, lda, "A") | check_gemm_shape(op_B, k, n, ldb, "B")) return 1;
   std::lock_guard<std::recursive_mutex> lock(h->mtx);
   return gemm_int8_real(h, op_A, op_B, m, n, k, 1.0, a, lda, b, ldb, 0.0, nullptr, m, (int)num_split, out);
@@ -985,7 +986,7 @@ int ozimmu_hip_split_int8(ozimmu_hip_handle_t h, int8_t *out_ptr, uint32_t ldo, 
     return 1;
   // src/split.cu:274-282: A: (m x n) = (rows x k) of op(A); B: (m x n) = (k x cols) of op(B)
   const OperandView v = matrix == OZIMMU_MATRIX_A ? view_A(op, m, n, in_ptr, ld) : view_B(op, m, n, in_ptr, ld);
-  if (ldo < v.K) return 1;
+  if (ldo < v.K || v.rows >= ((size_t)1 << 31) || v.K > ((size_t)1 << 30)) return 1;
   if (v.rows == 0) return 0;
   std::lock_guard<std::recursive_mutex> lock(h->mtx);
   const size_t exps_bytes = align256(4 * v.rows);
