@@ -103,41 +103,63 @@ __device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, cons
   double ea[WA];
 #pragma unroll
   for (int a = 0; a < WA; a++) ea[a] = (m0 + 32 * a < p.M) ? p.ea[m0 + 32 * a] : 0.0;
+  // Columns are processed CG at a time: the loads every product needs (eb[n], chained acc values) are issued first,
+  // then the CG * WA fma chains run interleaved, diagonal outermost.  With one wave per SIMD (wide kernel) nothing else
+  // hides a load's round trip or an FP64 chain's latency: the first, column-at-a-time form of this loop took 18 us per
+  // 96x128 tile (tools/gemm_ablate.hip, no-epilogue variant).  The sched_barrier keeps the work of later groups from
+  // being hoisted over the live accumulators (up to 432 registers).
+  constexpr int CG = 2;
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    __builtin_amdgcn_sched_barrier(0); // keep the per-column work from being hoisted over the live accumulators
-    const uint32_t n = nbase + (r & 3) + 8 * (r >> 2);
-    if (n >= p.N) continue;
-    const double ebn = p.final ? p.eb[n] : 0.0;
+  for (int r0 = 0; r0 < 16; r0 += CG) {
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t n[CG];
+    bool ok[CG][WA];
+    double x[CG][WA], ebn[CG];
 #pragma unroll
-    for (int a = 0; a < WA; a++) {
-      const uint32_t m = m0 + 32 * a;
-      if (m >= p.M) continue;
-      double x = p.acc_in ? p.acc[(size_t)n * p.M + m] : 0.0;
+    for (int rr = 0; rr < CG; rr++) {
+      const int r = r0 + rr;
+      n[rr] = nbase + (r & 3) + 8 * (r >> 2);
+      ebn[rr] = (p.final && n[rr] < p.N) ? p.eb[n[rr]] : 0.0;
 #pragma unroll
-      for (int d = 0; d < ND; d++) x = fma((double)acc(a, d, r), sc[d], x);
-      if (!p.final) {
-        p.acc[(size_t)n * p.M + m] = x;
-      } else {
+      for (int a = 0; a < WA; a++) {
+        const uint32_t m = m0 + 32 * a;
+        ok[rr][a] = n[rr] < p.N && m < p.M;
+        x[rr][a] = (ok[rr][a] && p.acc_in) ? p.acc[(size_t)n[rr] * p.M + m] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < ND; d++)
+#pragma unroll
+      for (int rr = 0; rr < CG; rr++)
+#pragma unroll
+        for (int a = 0; a < WA; a++) x[rr][a] = fma((double)acc(a, d, r0 + rr), sc[d], x[rr][a]);
+#pragma unroll
+    for (int rr = 0; rr < CG; rr++)
+#pragma unroll
+      for (int a = 0; a < WA; a++) {
+        if (!ok[rr][a]) continue;
+        const uint32_t m = m0 + 32 * a;
+        if (!p.final) {
+          p.acc[(size_t)n[rr] * p.M + m] = x[rr][a];
+          continue;
+        }
         // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
-        const double v = x * 0x1p-44 * ea[a] * ebn;
+        const double v = x[rr][a] * 0x1p-44 * ea[a] * ebn[rr];
         if (p.cplx) {
           // one of the four real products of a ZGEMM: C += (alpha_re + i alpha_im) * v  (axy_complex_kernel,
           // src/gemm.cu:160-186; C was scaled by beta beforehand, src/gemm.cu:199-239)
-          double2 *zp = reinterpret_cast<double2 *>(p.c) + ((size_t)n * p.ldc + m);
+          double2 *zp = reinterpret_cast<double2 *>(p.c) + ((size_t)n[rr] * p.ldc + m);
           double2 y = *zp;
           y.x = fma(p.alpha, v, y.x);
           y.y = fma(p.alpha_im, v, y.y);
           *zp = y;
-          continue;
-        }
-        double *cp = p.c + (size_t)n * p.ldc + m;
-        if (p.beta != 0.0)
+        } else if (p.beta != 0.0) {
+          double *cp = p.c + (size_t)n[rr] * p.ldc + m;
           *cp = fma(p.alpha, v, p.beta * *cp);
-        else
-          *cp = p.alpha * v;
+        } else {
+          p.c[(size_t)n[rr] * p.ldc + m] = p.alpha * v;
+        }
       }
-    }
   }
 }
 

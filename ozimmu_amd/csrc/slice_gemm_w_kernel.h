@@ -113,6 +113,7 @@ inline constexpr WSched<S, D0, ND, WA> kWSched{};
 constexpr int VARW_NA3 = 1;        // 3 A buffers (prefetch distance 2); else 2 (distance 1)
 constexpr int VARW_NO_GLOBAL = 2;  // ablation: no staging (LDS holds garbage)
 constexpr int VARW_MFMA_ONLY = 4;  // ablation: no LDS reads either
+constexpr int VARW_NO_EPILOGUE = 128; // measurement: accumulators are only kept alive, nothing is converted or stored
 constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..107 of the first 32 workgroups -> p.acc
 constexpr int VARW_BAND4 = 16;     // measurement: XCD patch of 4 (M) x 8 (N) tiles instead of 8 x 4
 constexpr int VARW_BAND16 = 32;    // measurement: 16 x 2
@@ -425,6 +426,13 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
     const int x = a * ND + d;
     return x < 16 ? accA[x < 16 ? x : 0][r] : accV[x >= 16 ? x - 16 : 0][r];
   };
+  if constexpr ((VARW & VARW_NO_EPILOGUE) != 0) {
+#pragma unroll
+    for (int x = 0; x < NACC_A; x++) asm volatile("" ::"a"(accA[x]));
+#pragma unroll
+    for (int x = 0; x < (NACC > 16 ? NACC_V : 0); x++) asm volatile("" ::"v"(accV[x]));
+    return;
+  }
   recombine_and_store<D0, ND, WA>(p, acc, rb0 * 32 + (lane & 31), tn * 128 + wave * 32 + 4 * (lane >> 5));
 }
 
