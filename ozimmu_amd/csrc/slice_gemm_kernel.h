@@ -73,6 +73,14 @@ __device__ __forceinline__ double pow2d(int e) {
   return __longlong_as_double((long long)(1023 + e) << 52);
 }
 
+// the value the other lane of the pair (2i, 2i+1) holds (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ double lane_pair_swap(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 // ---- epilogue shared by the kernels: INT32 diagonal sums -> FP64 -> C ---------------------------------------
 // acc[a][d] holds, in the MFMA 32x32 C/D register layout (lane&31 = m, 16 registers = 16 different n), the sum of
 // the slice products with i+j = D0+d of the a-th 32-row block of the wave (rows m0 + 32*a + (lane&31)).
@@ -80,7 +88,8 @@ __device__ __forceinline__ double pow2d(int e) {
 // outermost so that everything that depends on n only is computed once and dies before the next column: the wide
 // kernel (slice_gemm_w_kernel.h) arrives here with up to 432 live accumulator registers.
 // acc(a, d, r): register r of diagonal accumulator d of block a (all three are compile-time constants after unrolling).
-template <int D0, int ND, int WA, class Acc>
+// EPI (measurement only, tools/gemm_ablate.hip): 1 = everything but the stores, 2 = stores without the FP64 chains
+template <int D0, int ND, int WA, int EPI = 0, class Acc>
 __device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, const Acc &acc, uint32_t m0,
                                                     uint32_t nbase) {
   if (p.dump) { // test hook: raw INT32 diagonal sums, [ND][N][M]
@@ -109,6 +118,72 @@ __device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, cons
   // 96x128 tile (tools/gemm_ablate.hip, no-epilogue variant).  The sched_barrier keeps the work of later groups from
   // being hoisted over the live accumulators (up to 432 registers).
   constexpr int CG = 2;
+  // ---- interior blocks of a real GEMM: 16-byte stores ------------------------------------------------------
+  // A global store costs the CU ~70 cycles of issue whatever its width (guide T21), and in the MFMA layout a lane
+  // owns ONE row per register, so the plain form needs one 8-byte store per element (48 per wave and tile).  Here two
+  // neighbouring lanes (rows 2i, 2i+1) exchange one value of the column pair (n, n+1) of a group through DPP: the
+  // even lane ends up with rows 2i, 2i+1 of column n, the odd lane with the same rows of column n+1 - 16 contiguous
+  // bytes each, half as many stores (and loads of the old C).  Every element still goes through exactly the same
+  // operations in the same order, so the result is bit-identical to the plain form (tests/test_gpu_wide_kernel.py).
+  // Addresses: a uniform column pointer (SGPR pair) + one 32-bit lane offset + an immediate per 32-row block.
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t mu = __builtin_amdgcn_readfirstlane(m0 - (lane & 31u));        // first row of the wave's block
+  const uint32_t nu = __builtin_amdgcn_readfirstlane(nbase - 4u * (lane >> 5)); // first column of the wave's block
+  if (p.final && !p.cplx && mu + 32u * WA <= p.M && nu + 32u <= p.N && (p.ldc & 1u) == 0 && p.ldc < (1u << 26) &&
+      (reinterpret_cast<uintptr_t>(p.c) & 15u) == 0) {
+    const bool odd = (lane & 1u) != 0;
+    const uint32_t boff = ((4u * (lane >> 5) + (lane & 1u)) * (uint32_t)p.ldc + (lane & 30u)) * 8u;
+    const double *eb_lane = p.eb + nu + 4u * (lane >> 5);
+    const bool rmw = p.beta != 0.0;
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += CG) {
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t cofs = (r0 & 3) + 8 * (r0 >> 2); // column of register r0 inside the block (lanes 32..63: + 4)
+      char *colp = reinterpret_cast<char *>(p.c + ((size_t)(nu + cofs) * p.ldc + mu)); // wave-uniform
+      double2 old[WA];
+      if (rmw) {
+#pragma unroll
+        for (int a = 0; a < WA; a++) old[a] = *reinterpret_cast<const double2 *>(colp + (size_t)boff + 256 * a);
+      }
+      const double eb0 = eb_lane[cofs], eb1 = eb_lane[cofs + 1];
+      double x0[WA], x1[WA];
+#pragma unroll
+      for (int a = 0; a < WA; a++) x0[a] = x1[a] = 0.0;
+      if (p.acc_in) { // later diagonal pass / K chunk: continue the chain the previous launch left in the workspace
+        const double *ap = p.acc + ((size_t)(nbase + cofs) * p.M + m0);
+#pragma unroll
+        for (int a = 0; a < WA; a++) x0[a] = ap[32 * a], x1[a] = ap[p.M + 32 * a];
+      }
+#pragma unroll
+      for (int d = 0; d < ND; d++)
+#pragma unroll
+        for (int a = 0; a < WA; a++) {
+          x0[a] = fma((double)acc(a, d, r0), sc[d], x0[a]);
+          x1[a] = fma((double)acc(a, d, r0 + 1), sc[d], x1[a]);
+        }
+#pragma unroll
+      for (int a = 0; a < WA; a++) {
+        // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
+        const double v0 = x0[a] * 0x1p-44 * ea[a] * eb0, v1 = x1[a] * 0x1p-44 * ea[a] * eb1;
+        const double s0 = lane_pair_swap(v0), s1 = lane_pair_swap(v1);
+        double2 y;
+        y.x = odd ? s1 : v0; // row 2i:     (column n from this lane | column n+1 from the even neighbour)
+        y.y = odd ? v1 : s0; // row 2i + 1: (column n from the odd neighbour | column n+1 from this lane)
+        if (rmw) {
+          y.x = fma(p.alpha, y.x, p.beta * old[a].x);
+          y.y = fma(p.alpha, y.y, p.beta * old[a].y);
+        } else {
+          y.x = p.alpha * y.x;
+          y.y = p.alpha * y.y;
+        }
+        if constexpr ((EPI & 1) != 0) {
+          if (y.x != 0x1.23456789p-900) continue; // never true for real data; keeps the chain alive
+        }
+        *reinterpret_cast<double2 *>(colp + (size_t)boff + 256 * a) = y;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r0 = 0; r0 < 16; r0 += CG) {
     __builtin_amdgcn_sched_barrier(0);
@@ -132,12 +207,18 @@ __device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, cons
 #pragma unroll
       for (int rr = 0; rr < CG; rr++)
 #pragma unroll
-        for (int a = 0; a < WA; a++) x[rr][a] = fma((double)acc(a, d, r0 + rr), sc[d], x[rr][a]);
+        for (int a = 0; a < WA; a++) {
+          if constexpr ((EPI & 2) != 0) x[rr][a] = __hiloint2double(acc(a, d, r0 + rr), __double2hiint(x[rr][a]) ^ __double2loint(x[rr][a]));
+          else x[rr][a] = fma((double)acc(a, d, r0 + rr), sc[d], x[rr][a]);
+        }
 #pragma unroll
     for (int rr = 0; rr < CG; rr++)
 #pragma unroll
       for (int a = 0; a < WA; a++) {
         if (!ok[rr][a]) continue;
+        if constexpr ((EPI & 1) != 0) {
+          if (x[rr][a] != 0x1.23456789p-900) continue; // never true for real data; keeps the chain alive
+        }
         const uint32_t m = m0 + 32 * a;
         if (!p.final) {
           p.acc[(size_t)n[rr] * p.M + m] = x[rr][a];

@@ -114,6 +114,8 @@ constexpr int VARW_NA3 = 1;        // 3 A buffers (prefetch distance 2); else 2 
 constexpr int VARW_NO_GLOBAL = 2;  // ablation: no staging (LDS holds garbage)
 constexpr int VARW_MFMA_ONLY = 4;  // ablation: no LDS reads either
 constexpr int VARW_NO_EPILOGUE = 128; // measurement: accumulators are only kept alive, nothing is converted or stored
+constexpr int VARW_EPI_NOSTORE = 256; // measurement: epilogue without its stores
+constexpr int VARW_EPI_NOCHAIN = 512; // measurement: epilogue without its FP64 chains
 constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..107 of the first 32 workgroups -> p.acc
 constexpr int VARW_BAND4 = 16;     // measurement: XCD patch of 4 (M) x 8 (N) tiles instead of 8 x 4
 constexpr int VARW_BAND16 = 32;    // measurement: 16 x 2
@@ -422,9 +424,14 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   for (; it < nk; it++) step(std::false_type{}, std::false_type{});
 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA (16 passes) -> VALU reads of its accumulator
-  auto acc = [&](int a, int d, int r) {
+  // One explicit v_accvgpr_read per element: left to itself the compiler copies the whole remaining part of a 16-register
+  // AGPR tuple to VGPRs for every element it extracts (5x the reads, plus spills).
+  auto acc = [&](int a, int d, int r) -> int {
     const int x = a * ND + d;
-    return x < 16 ? accA[x < 16 ? x : 0][r] : accV[x >= 16 ? x - 16 : 0][r];
+    if (x >= 16) return accV[x >= 16 ? x - 16 : 0][r];
+    int v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(accA[x < 16 ? x : 0][r]));
+    return v;
   };
   if constexpr ((VARW & VARW_NO_EPILOGUE) != 0) {
 #pragma unroll
@@ -433,7 +440,7 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
     for (int x = 0; x < (NACC > 16 ? NACC_V : 0); x++) asm volatile("" ::"v"(accV[x]));
     return;
   }
-  recombine_and_store<D0, ND, WA>(p, acc, rb0 * 32 + (lane & 31), tn * 128 + wave * 32 + 4 * (lane >> 5));
+  recombine_and_store<D0, ND, WA, (VARW >> 8) & 3>(p, acc, rb0 * 32 + (lane & 31), tn * 128 + wave * 32 + 4 * (lane >> 5));
 }
 
 // contiguous run of logical ids for XCD x out of n (bijective form of the guide's T1 swizzle)

@@ -157,3 +157,35 @@ def test_wide_zgemm_bit_exact(oz, op_a, op_b):
     assert st == 0
     assert O.zgemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
     np.testing.assert_array_equal(zbits(c.download()), zbits(c_ref.view))
+
+
+@pytest.mark.parametrize("kernel", ["wide", "classic"])
+@pytest.mark.parametrize("ld_extra,c_offset", [(0, 0), (2, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (-0.5, 2.0)])
+@pytest.mark.parametrize("S", [9, 13])
+def test_epilogue_store_forms_agree_with_the_oracle(oz, monkeypatch, kernel, ld_extra, c_offset, alpha, beta, S):
+    """the epilogue stores interior blocks of a real GEMM as 16-byte row pairs (lane-pair exchange) when ldc is even and
+    C is 16-byte aligned, and element by element otherwise or at the edges: an odd ldc, a C that starts 8 bytes off, and
+    ragged edges (m, n not multiples of the tile) must all give the oracle's bits, with and without the read of C,
+    in one pass (S = 9) and when a second diagonal pass continues the chain from the workspace (S = 13)"""
+    import torch
+    m_, h = oz
+    monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", kernel)
+    m, n, k = 262, 301, 96
+    ld = m + ld_extra
+    rng = np.random.default_rng(17 + ld_extra + 2 * c_offset + S)
+    a = operand("N", m, k, rng)
+    b = operand("N", k, n, rng)
+    c_ref = ColMajor(m, n, ld=ld, fill=uniform_pm1, rng=rng)
+    flat = torch.full((n * ld + c_offset + 1,), float("nan"), dtype=torch.float64, device="cuda")
+    flat[c_offset:c_offset + n * ld] = torch.from_numpy(c_ref.buf.reshape(-1)).cuda()
+    c_ptr = flat.data_ptr() + 8 * c_offset
+    assert m_.gemm(h, "N", "N", m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c_ptr, ld, f"fp64_int8_{S}") == 0
+    _sync()
+    assert O.gemm("N", "N", m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    got = flat[c_offset:c_offset + n * ld].cpu().numpy().reshape(n, ld)
+    np.testing.assert_array_equal(np.ascontiguousarray(got.T[:m]).view(np.uint64),
+                                  np.ascontiguousarray(c_ref.view).view(np.uint64))
+    if ld > m:
+        assert np.isnan(got[:, m:]).all()  # ld padding untouched
+    assert np.isnan(flat[:c_offset].cpu().numpy()).all() and np.isnan(flat[c_offset + n * ld:].cpu().numpy()).all()

@@ -176,6 +176,8 @@ int main(int argc, char **argv) {
       {"wide 96x128 pd1 mixed persistent+steal", run_w<S, 3, 0, 0, -1, 4, 6, true, true>, false, {}},
       {"wide 96x128 pd1 persistent+steal", run_w<S, 3, 0, 0, -1, 4, 6, false, true>, false, {}},
       {"wide pd1 mixed persistent no-epilogue", run_w<S, 3, VARW_NO_EPILOGUE, 0, -1, 4, 6, true, true>, false, {}},
+      {"wide pd1 mixed persistent epilogue w/o stores", run_w<S, 3, VARW_EPI_NOSTORE, 0, -1, 4, 6, true, true>, false, {}},
+      {"wide pd1 mixed persistent epilogue w/o chains", run_w<S, 3, VARW_EPI_NOCHAIN, 0, -1, 4, 6, true, true>, false, {}},
       {"wide 96x128 pd1 mixed dma every 6", run_w<S, 3, 0, 0, -1, 6, 6, true>, false, {}},
       {"wide 96x128 pd1 mixed tail 10", run_w<S, 3, 0, 0, -1, 4, 10, true>, false, {}},
       {"wide 96x128 no-global", run_w<S, 3, VARW_NA3 | VARW_NO_GLOBAL>, false, {}},
