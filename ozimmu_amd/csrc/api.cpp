@@ -213,22 +213,29 @@ struct BatchSpec {
 
 // zero the exponent words (and phase hints) at the head of `count` workspace slots
 static bool zero_slot_heads(ozimmu_hip_handle_t h, void *base, size_t head_bytes, size_t slot_bytes, size_t count) {
-  if (count == 1) return hip_ok(hipMemsetAsync(base, 0, head_bytes, h->stream), "memset");
-  return hip_ok(hipMemset2DAsync(base, slot_bytes, 0, head_bytes, count, h->stream), "memset2d");
+  return hip_ok(launch_zero_words(base, head_bytes, slot_bytes, (uint32_t)count, h->stream), "zero_words");
 }
 
 // Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
+// Consecutive calls on one stream are ordered by the stream.  When a call arrives on a DIFFERENT stream than the
+// previous one, the event is recorded on the previous stream at that moment (it then covers everything the earlier
+// call enqueued) and the new stream waits for it: no event per call - a recorded event costs every call ~6 us of
+// dispatch gap in front of its first kernel (rocprofv3 kernel trace, 1024^3), a tenth of a small GEMM.  If the earlier
+// stream no longer exists (hipEventRecord rejects it) the device is synchronised instead.
 struct WorkspaceUse {
   ozimmu_hip_handle_t h;
   explicit WorkspaceUse(ozimmu_hip_handle_t handle) : h(handle) {
-    if (h->tail_valid && h->tail_stream != h->stream && !getenv("OZIMMU_HIP_TEST_NO_STREAM_ORDER"))
-      hipStreamWaitEvent(h->stream, h->tail_ev, 0);
+    if (h->tail_valid && h->tail_stream != h->stream && !getenv("OZIMMU_HIP_TEST_NO_STREAM_ORDER")) {
+      if (h->tail_ev && hipEventRecord(h->tail_ev, h->tail_stream) == hipSuccess &&
+          hipStreamWaitEvent(h->stream, h->tail_ev, 0) == hipSuccess)
+        return;
+      (void)hipGetLastError();
+      hipDeviceSynchronize();
+    }
   }
   ~WorkspaceUse() {
-    if (h->tail_ev && hipEventRecord(h->tail_ev, h->stream) == hipSuccess) {
-      h->tail_stream = h->stream;
-      h->tail_valid = true;
-    }
+    h->tail_stream = h->stream;
+    h->tail_valid = true;
   }
 };
 
@@ -265,7 +272,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   const bool use_phase = bs.count == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false);
   if (one_pass_split(8 * (m + n) * k * bs.count)) {
     // both operands (and every matrix of the batch) in one launch; only the phase hint words need zeroing
-    if (use_phase && !hip_ok(hipMemsetAsync(w.phase, 0, 8 * 256, h->stream), "memset")) return 3;
+    if (use_phase && !hip_ok(launch_zero_words(w.phase, 8 * 256, 0, 1, h->stream), "zero_words")) return 3;
     const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, nullptr},
                               {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, nullptr}};
     if (!hip_ok(launch_split_fused(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot), "split")) return 3;
@@ -401,7 +408,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
   const bool use_phase = bs.count == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false);
   if (one_pass_split(16 * (m + n) * k * bs.count)) {
-    if (use_phase && !hip_ok(hipMemsetAsync(w.phase, 0, 8 * 256, h->stream), "memset")) return 3;
+    if (use_phase && !hip_ok(launch_zero_words(w.phase, 8 * 256, 0, 1, h->stream), "zero_words")) return 3;
     const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, nullptr},
                               {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, nullptr},
                               {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, nullptr},

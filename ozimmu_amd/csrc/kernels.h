@@ -90,6 +90,8 @@ struct SplitJobs {
   size_t ws_stride;
 };
 // the two streaming passes for up to 4 views x `batch` matrices in one launch each (small problems: launch bound)
+// zero `bytes` at the head of `count` workspace slots `pitch` bytes apart (exponent words, phase hints, claim counters)
+hipError_t launch_zero_words(void *base, size_t bytes, size_t pitch, uint32_t count, hipStream_t stream);
 hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stream, uint32_t batch = 1,
                                 size_t ws_stride = 0);
 hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch = 1,

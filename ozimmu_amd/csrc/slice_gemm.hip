@@ -28,6 +28,7 @@
 #include <cstring>
 #include <map>
 
+#include "slice_gemm_k2_kernel.h"
 #include "slice_gemm_w_kernel.h"
 
 namespace ozhip {
@@ -79,6 +80,20 @@ static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   const uint32_t nb = a.tiles_m * a.tiles_n;
   hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>), dim3(nb, a.batch > 1 ? a.batch : 1),
                      dim3(128 * WM), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ---- K-split kernel: one 8-wave workgroup per CU, 64x64 tiles, for launches with no more tiles than CUs --------------
+template <int S, int D0, int ND>
+static hipError_t launch_k2(const SliceGemmArgs &a0, hipStream_t stream) {
+  using Cfg = K2Cfg<S, D0, ND>;
+  SliceGemmArgs a = a0;
+  a.tiles_m = (a.M + 63) / 64;
+  a.tiles_n = (a.N + 63) / 64;
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_k2_kernel<S, D0, ND>, Cfg::LDS, attr_done)) return e;
+  hipLaunchKernelGGL((slice_gemm_k2_kernel<S, D0, ND>), dim3(a.tiles_m * a.tiles_n, a.batch > 1 ? a.batch : 1), dim3(512),
+                     Cfg::LDS, stream, a);
   return hipGetLastError();
 }
 
@@ -208,6 +223,14 @@ static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
   // S <= 4: few MFMAs per staged byte even on 128x128 tiles; the classic 8-wave 128x64 kernel measures faster
   // (4096^3: S=3 241 vs 214, S=4 174 vs 168 TFLOP/s; from S=5 on the wide kernel leads by 6-13 %)
   constexpr bool wide_pays = ND >= 5 || D0 > 0;
+  if constexpr (K2Cfg<S, D0, ND>::ok) {
+    // no more 64x64 tiles than CUs (all matrices of a batch together): the classic kernel would run one wave per SIMD;
+    // split K inside an 8-wave workgroup instead (slice_gemm_k2_kernel.h; 1024^3 S=9: 48.6 -> see DESIGN.md)
+    const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL");
+    const uint64_t wgs = (uint64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.batch > 1 ? a.batch : 1);
+    if (e ? !std::strcmp(e, "k2") : (wgs <= (uint64_t)cu_count() && a.kb1 - a.kb0 >= 4))
+      return launch_k2<S, D0, ND>(a, stream);
+  }
   if (WideCfg<S, D0, ND>::ok && (wide_pays || getenv("OZIMMU_HIP_GEMM_KERNEL"))) {
     const int ncu = cu_count();
     // a strided batch fills the chip with all its matrices: plan one matrix on the CUs it gets on average

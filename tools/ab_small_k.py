@@ -1,0 +1,21 @@
+"""Slice-GEMM stage time of a 1024 x 1024 x K product vs K for the kernels a small problem can run on (stage events of
+the library's profiler): separates the per-launch fixed cost from the per-k-step cost."""
+import os, sys, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+oz.enable_profiling(h)
+mn = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+for kernel in ["k2", "classic", "wide"]:
+    os.environ["OZIMMU_HIP_GEMM_KERNEL"] = kernel
+    for K in [256, 1024, 2048, 4096, 8192]:
+        a = torch.rand(K, mn, dtype=torch.float64, device="cuda") * 2 - 1
+        b = torch.rand(mn, K, dtype=torch.float64, device="cuda") * 2 - 1
+        c = torch.zeros(mn, mn, dtype=torch.float64, device="cuda")
+        ts = []
+        for i in range(12):
+            assert oz.gemm(h, "N", "N", mn, mn, K, 1.0, a, mn, b, K, 0.0, c, mn, "fp64_int8_9") == 0
+            if i >= 4: ts.append(oz.last_stage_ms(h)["int8tc"] * 1e3)
+        ts.sort()
+        t = ts[len(ts) // 2]
+        print(f"{kernel:8s} {mn}x{mn}x{K}: gemm stage {t:8.1f} us  ({t / (K / 32):6.3f} us per k-block, {45 * 2 * mn * mn * K / t / 1e6:7.1f} TOPS)")

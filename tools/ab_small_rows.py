@@ -9,15 +9,15 @@ b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
 c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
 def call(): assert oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, "fp64_int8_9") == 0
 res = {}
-opts = [None, "0", "8", "20", "32", "44", "68", "128"]
+opts = [None] + (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "8", "20", "32", "44", "68", "128"])
 for r in range(4):
     for o in opts:
         if o is None: os.environ.pop("OZIMMU_HIP_WIDE_SMALL_ROWS", None)
         else: os.environ["OZIMMU_HIP_WIDE_SMALL_ROWS"] = o
         call(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5): call()
+        for _ in range(20): call()
         torch.cuda.synchronize()
-        res.setdefault(o, []).append((time.perf_counter() - t0) / 5)
+        res.setdefault(o, []).append((time.perf_counter() - t0) / 20)
 for o in opts:
     v = sorted(res[o]); print(f"small rows {o}: median {v[len(v)//2]*1e3:.3f} ms  min {v[0]*1e3:.3f} ms  ({2*n**3/v[len(v)//2]/1e12:.1f} TF)")

@@ -1,0 +1,23 @@
+"""Whole-call A/B of the split forms at small sizes (back-to-back calls, wall clock over 200 calls)."""
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+variants = {"two-pass multi-view (default)": {}, "one-pass": {"OZIMMU_HIP_SPLIT_ONE_PASS_BYTES": str(1 << 40)}}
+keys = ["OZIMMU_HIP_SPLIT_ONE_PASS_BYTES"]
+for n in [int(x) for x in sys.argv[1:]] or [1024, 1536, 2048]:
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    def call(): assert oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, "fp64_int8_9") == 0
+    res = {}
+    for r in range(3):
+        for name, env in variants.items():
+            for k in keys: os.environ.pop(k, None)
+            os.environ.update(env)
+            for _ in range(10): call()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(200): call()
+            torch.cuda.synchronize(); res.setdefault(name, []).append((time.perf_counter() - t0) / 200 * 1e6)
+    for name, v in res.items():
+        v = sorted(v); print(f"n={n} {name}: {v[1]:.1f} us/call ({2 * n**3 / v[1] / 1e6:.1f} TF)")

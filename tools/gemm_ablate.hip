@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -166,6 +167,53 @@ int main(int argc, char **argv) {
     bool nophase;
     std::vector<float> ms;
   };
+#ifdef ABLATE_SMALL_TILES // -DABLATE_SMALL_TILES: the 64x128 / 32x128 forms of the wide kernel (problems of ~2 tiles per CU)
+  std::vector<Var> vars = {
+      {"wide 64x128 persistent dma every 4 (shipped)", run_w<S, 2, 0, 0, -1, 4, 6, false, true>, false, {}},
+      {"wide 64x128 persistent dma every 3", run_w<S, 2, 0, 0, -1, 3, 6, false, true>, false, {}},
+      {"wide 64x128 persistent dma every 2", run_w<S, 2, 0, 0, -1, 2, 6, false, true>, false, {}},
+      {"wide 64x128 persistent dma every 1", run_w<S, 2, 0, 0, -1, 1, 6, false, true>, false, {}},
+      {"wide 64x128 persistent dma every 2 tail 10", run_w<S, 2, 0, 0, -1, 2, 10, false, true>, false, {}},
+      {"wide 64x128 persistent dma every 2 from slot 1", run_w<S, 2, 0, 0, 1, 2, 6, false, true>, false, {}},
+      {"wide 64x128 persistent pd2 dma every 4", run_w<S, 2, VARW_NA3, 0, -1, 4, 6, false, true>, false, {}},
+      {"wide 64x128 persistent pd2 dma every 2", run_w<S, 2, VARW_NA3, 0, -1, 2, 6, false, true>, false, {}},
+      {"wide 64x128 persistent no-global", run_w<S, 2, VARW_NO_GLOBAL, 0, -1, 4, 6, false, true>, false, {}},
+      {"wide 64x128 persistent mfma-only", run_w<S, 2, VARW_MFMA_ONLY, 0, -1, 4, 6, false, true>, false, {}},
+      {"wide 96x128 persistent (shipped)", run_w<S, 3, 0, 0, -1, 4, 6, false, true>, false, {}},
+      {"wide 32x128 static", run_w<S, 1, 0, 0, -1, 4, 6, false, false>, false, {}},
+      {"wide 32x128 persistent", run_w<S, 1, 0, 0, -1, 4, 6, false, true>, false, {}},
+      {"wide 32x128 static tail 10", run_w<S, 1, 0, 0, -1, 4, 10, false, false>, false, {}},
+      {"wide 32x128 static pd2", run_w<S, 1, VARW_NA3, 0, -1, 4, 6, false, false>, false, {}},
+      {"wide 32x128 static mfma-only", run_w<S, 1, VARW_MFMA_ONLY, 0, -1, 4, 6, false, false>, false, {}},
+      {"wide 64x128 static", run_w<S, 2, 0, 0, -1, 4, 6, false, false>, false, {}},
+      {"classic 64x64", run<S, VAR_SHIPPED>, false, {}},
+  };
+  for (int r = 0; r < rounds + 1; r++)
+    for (auto &v : vars) {
+      const float ms = v.fn(a, st, e0, e1);
+      if (r > 0) v.ms.push_back(ms);
+    }
+  { // bitwise cross-check of the candidates against the plain loop
+    std::vector<double> c0(M * N), c1(M * N);
+    run<S, 0>(a, st, e0, e1);
+    CK(hipMemcpy(c0.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
+    for (int which = 0; which < 3; which++) {
+      CK(hipMemset(C, 0xFF, 8 * M * N));
+      if (which == 0) run_w<S, 2, 0, 0, -1, 2, 6, false, true>(a, st, e0, e1);
+      if (which == 1) run_w<S, 2, 0, 0, -1, 1, 6, false, true>(a, st, e0, e1);
+      if (which == 2) run_w<S, 1, 0, 0, -1, 4, 6, false, false>(a, st, e0, e1);
+      CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
+      printf("candidate %d vs plain loop: %s\n", which, std::memcmp(c0.data(), c1.data(), 8 * M * N) ? "MISMATCH" : "bitwise equal");
+    }
+  }
+  for (auto &v : vars) {
+    std::sort(v.ms.begin(), v.ms.end());
+    const double ops = 45.0 * 2.0 * M * N * K;
+    printf("%s median %8.3f ms (%7.1f TOPS)   min %8.3f ms (%7.1f TOPS)\n", v.name, v.ms[v.ms.size() / 2],
+           ops / v.ms[v.ms.size() / 2] / 1e9, v.ms[0], ops / v.ms[0] / 1e9);
+  }
+  return 0;
+#else
   std::vector<Var> vars = {
       {"shipped 64x64 + throttle", run_throttled<S, VAR_SHIPPED>, false, {}},
       {"wide 96x128 pd2", run_w<S, 3, VARW_NA3>, false, {}},
@@ -294,4 +342,5 @@ int main(int argc, char **argv) {
                 ops / mn / 1e9);
   }
   return 0;
+#endif
 }
