@@ -239,7 +239,21 @@ struct WorkspaceUse {
   }
 };
 
+static bool stream_is_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st != hipStreamCaptureStatusNone;
+}
+
 static bool ensure_workspace(ozimmu_hip_handle_t h, size_t bytes) {
+  // growing the workspace (hipFree / hipMalloc) is illegal while the caller's stream is being captured into a graph and
+  // would invalidate the capture: report "failed, C untouched" instead (the interposer then captures the vendor GEMM);
+  // once the workspace is large enough, every launch of the call is an ordinary capturable kernel
+  if (bytes > h->current_working_memory_size && h->malloc_mode == OZIMMU_MALLOC_SYNC && stream_is_capturing(h->stream))
+    return false;
   ozimmu_hip_reallocate_working_memory(h, bytes);
   return h->working_memory_ptr != nullptr && h->current_working_memory_size >= bytes;
 }
@@ -799,6 +813,7 @@ static int mantissa_loss_impl(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, oz
   const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/split.cu:461
   const int parts = cplx ? 2 : 1;
   const size_t ea = align256(4 * m), eb = align256(4 * n), exps_bytes = parts * (ea + eb);
+  if (stream_is_capturing(h->stream)) return 3; // the statistic is read back on the host: not capturable into a graph
   WorkspaceUse use(h);
   if (!ensure_workspace(h, exps_bytes)) return 3;
   char *base = (char *)h->working_memory_ptr;
@@ -880,6 +895,11 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
   const bool vendor_only = k == 0 || alpha_zero || bits_for_k(k) == 0 || m >= ((size_t)1 << 31) || n >= ((size_t)1 << 31);
 
   if (mode == OZIMMU_FP64_INT8_AUTO && !vendor_only) { // src/gemm.cu:628-638
+    {
+      // the statistic is read back on the host (blocking copy): impossible while the stream is captured into a graph
+      std::lock_guard<std::recursive_mutex> lock(h->mtx);
+      if (stream_is_capturing(h->stream)) return 3;
+    }
     const ozimmu_compute_mode_t auto_mode = ozimmu_hip_auto_mode_select(
         h, op_A, op_B, m, n, k, a, lda, b, ldb, element_kind, h->avg_mantissa_loss_threshold);
     log_info(std::string("AUTO selected mode = ") + ozimmu_hip_get_compute_mode_name_str(auto_mode) +

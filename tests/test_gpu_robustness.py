@@ -307,3 +307,54 @@ def test_baseline_config_c1_fp64_int8_6_512_cubed(oz):
     np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
     r = O.relative_residual_sampled("N", "N", m, n, k, a.view, b.view, c.view, ns=2048)
     assert 1e-12 < r < 1e-10         # six 7-bit slices: the accuracy level of BASELINE.md's curve at S=6
+
+
+def test_gemm_is_capturable_into_a_graph_once_the_workspace_exists(oz):
+    """PyTorch-style graph capture of the caller's stream: with a workspace that is already large enough every launch of
+    a call is an ordinary kernel, so the captured graph replays the same bits; a call that would have to GROW the
+    workspace during capture (hipMalloc / hipFree are illegal there) reports "failed, C untouched" (status 3: the
+    interposer would capture the vendor GEMM instead) and leaves the capture valid; fp64_int8_auto reads a statistic
+    back on the host and is refused the same way"""
+    import torch
+    import ozimmu_amd as m_
+    m, n, k, S = 300, 260, 200, 9
+    rng = np.random.default_rng(77)
+    a = operand("N", m, k, rng)
+    b = operand("N", k, n, rng)
+    c_ref = ColMajor(m, n)
+    assert O.gemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    h = m_.create()
+    try:
+        s = torch.cuda.Stream()
+        c = torch.zeros(n, m, dtype=torch.float64, device="cuda")
+        a.dev, b.dev
+        torch.cuda.synchronize()
+        # 1) fresh handle, no workspace yet: the captured call is refused, the capture survives
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, stream=s):
+            st_grow = m_.gemm_on_stream(h, torch.cuda.current_stream(), "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld,
+                                        0.0, c, m, f"fp64_int8_{S}")
+            st_auto = m_.gemm_on_stream(h, torch.cuda.current_stream(), "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld,
+                                        0.0, c, m, "fp64_int8_auto")
+            c.add_(1.0)  # something capturable so that the graph is not empty
+        assert st_grow == 3 and st_auto == 3
+        g0.replay()
+        torch.cuda.synchronize()
+        assert float(c.min()) == 1.0 and float(c.max()) == 1.0  # C untouched by the refused calls
+        # 2) eager call grows the workspace; the same call is then captured and replayed
+        with torch.cuda.stream(s):
+            assert m_.gemm_on_stream(h, s, "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c, m, f"fp64_int8_{S}") == 0
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=s):
+            st = m_.gemm_on_stream(h, torch.cuda.current_stream(), "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0,
+                                   c, m, f"fp64_int8_{S}")
+        assert st == 0
+        for _ in range(2):
+            c.fill_(float("nan"))
+            g1.replay()
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(c.cpu().numpy().view(np.uint64), c_ref.buf.view(np.uint64))
+    finally:
+        torch.cuda.synchronize()
+        m_.destroy(h)
