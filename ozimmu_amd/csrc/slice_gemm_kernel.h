@@ -184,6 +184,56 @@ __device__ __forceinline__ void recombine_and_store(const SliceGemmArgs &p, cons
     }
     return;
   }
+  // ---- interior blocks of one of the four real products of a ZGEMM ------------------------------------------------
+  // C is interleaved complex: an element is 16 bytes, read and written back by the lane that owns it.  Same uniform
+  // column pointer + 32-bit lane offset addressing as above, no per-element bounds checks and branches (the plain
+  // form below spends 64-bit address arithmetic and an exec-mask dance on every element).
+  if (p.final && p.cplx && mu + 32u * WA <= p.M && nu + 32u <= p.N && p.ldc < (1u << 25)) {
+    const uint32_t boff = (4u * (lane >> 5) * (uint32_t)p.ldc + (lane & 31u)) * 16u;
+    const double *eb_lane = p.eb + nu + 4u * (lane >> 5);
+    const size_t col_bytes = p.ldc * 16u;
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += CG) {
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t cofs = (r0 & 3) + 8 * (r0 >> 2);
+      char *colp = reinterpret_cast<char *>(reinterpret_cast<double2 *>(p.c) + ((size_t)(nu + cofs) * p.ldc + mu));
+      double2 old0[WA], old1[WA];
+#pragma unroll
+      for (int a = 0; a < WA; a++) {
+        old0[a] = *reinterpret_cast<const double2 *>(colp + (size_t)boff + 512 * a);
+        old1[a] = *reinterpret_cast<const double2 *>(colp + col_bytes + (size_t)boff + 512 * a);
+      }
+      const double eb0 = eb_lane[cofs], eb1 = eb_lane[cofs + 1];
+      double x0[WA], x1[WA];
+#pragma unroll
+      for (int a = 0; a < WA; a++) x0[a] = x1[a] = 0.0;
+      if (p.acc_in) {
+        const double *ap = p.acc + ((size_t)(nbase + cofs) * p.M + m0);
+#pragma unroll
+        for (int a = 0; a < WA; a++) x0[a] = ap[32 * a], x1[a] = ap[p.M + 32 * a];
+      }
+#pragma unroll
+      for (int d = 0; d < ND; d++)
+#pragma unroll
+        for (int a = 0; a < WA; a++) {
+          x0[a] = fma((double)acc(a, d, r0), sc[d], x0[a]);
+          x1[a] = fma((double)acc(a, d, r0 + 1), sc[d], x1[a]);
+        }
+#pragma unroll
+      for (int a = 0; a < WA; a++) {
+        const double v0 = x0[a] * 0x1p-44 * ea[a] * eb0, v1 = x1[a] * 0x1p-44 * ea[a] * eb1;
+        // C += (alpha_re + i alpha_im) * v  (axy_complex_kernel, src/gemm.cu:160-186)
+        double2 y0 = old0[a], y1 = old1[a];
+        y0.x = fma(p.alpha, v0, y0.x);
+        y0.y = fma(p.alpha_im, v0, y0.y);
+        y1.x = fma(p.alpha, v1, y1.x);
+        y1.y = fma(p.alpha_im, v1, y1.y);
+        *reinterpret_cast<double2 *>(colp + (size_t)boff + 512 * a) = y0;
+        *reinterpret_cast<double2 *>(colp + col_bytes + (size_t)boff + 512 * a) = y1;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r0 = 0; r0 < 16; r0 += CG) {
     __builtin_amdgcn_sched_barrier(0);
