@@ -111,9 +111,10 @@ struct WideCfg {
   static constexpr int WA = (regs_ok(4) && lds(4, 2) <= LDS_MAX)   ? 4
                             : (regs_ok(3) && lds(3, 2) <= LDS_MAX) ? 3
                             : (regs_ok(2) && lds(2, 2) <= LDS_MAX) ? 2
+                            : (regs_ok(1) && lds(1, 2) <= LDS_MAX) ? 1 // 14..16 staged slices (second pass of S = 14..16)
                                                                    : 0;
   static constexpr int NA = 2;
-  static constexpr bool ok = WA >= 2;
+  static constexpr bool ok = WA >= 1;
 };
 
 // Rows of full-height (WA blocks) and reduced (WA-1 blocks) tiles that cover `rows32` 32-row blocks with the smallest

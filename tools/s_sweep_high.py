@@ -1,0 +1,17 @@
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+n = 4096
+a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+for S in range(12, 19):
+    for kern in (None, "classic"):
+        if kern: os.environ["OZIMMU_HIP_GEMM_KERNEL"] = kern
+        else: os.environ.pop("OZIMMU_HIP_GEMM_KERNEL", None)
+        def call(): assert oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, f"fp64_int8_{S}") == 0
+        call(); call(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(6): call()
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 6
+        print(f"S={S} {kern or 'default'}: {2*n**3/t/1e12:.1f} TF", flush=True)
