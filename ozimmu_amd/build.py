@@ -4,6 +4,7 @@
 
 The .so is git-ignored but travels with the tree (gpurun snapshot); nothing is installed or JIT-cached.
 """
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -12,8 +13,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libozimmu_hip.so")
-SOURCES = ["slice_gemm.hip", "split.hip", "convert.hip", "api.cpp", "interpose.cpp"]
-HEADERS = ["kernels.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
+GEMM_PARTS = ["slice_gemm_s3_8.hip", "slice_gemm_s9_11.hip", "slice_gemm_s12_14.hip", "slice_gemm_s15_18.hip"]
+SOURCES = GEMM_PARTS + ["slice_gemm.hip", "split.hip", "convert.hip", "api.cpp", "interpose.cpp"]
+HEADERS = ["kernels.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", "slice_gemm_k2_kernel.h",
+           "slice_gemm_launch.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
 ARCH = "gfx950"
 
 
@@ -31,23 +34,42 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def device_asm_path(source):
+    """where the build leaves the gfx950 assembly of a .hip source (read by tests/test_isa_invariants.py)"""
+    return os.path.join(HERE, "build", source.rsplit(".", 1)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def _compile(hipcc, common, s, verbose):
+    src = os.path.join(CSRC, s)
+    stem = s.rsplit(".", 1)[0]
+    obj = os.path.join(HERE, "build", stem + ".o")
+    # -save-temps=obj keeps the device assembly (device_asm_path) that the ISA test inspects, so that the test does not
+    # compile the kernels a second time; the other intermediates are deleted again (tens of MB)
+    dev = ["-x", "hip", f"--offload-arch={ARCH}", "-save-temps=obj"] if s.endswith(".hip") else []
+    cmd = [hipcc] + common + dev + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    keep = {obj, device_asm_path(s)}
+    for f in os.listdir(os.path.join(HERE, "build")):
+        path = os.path.join(HERE, "build", f)
+        if (f.startswith(stem + "-h") or f.startswith(stem + ".hip-")) and path not in keep:
+            os.remove(path)
+    return obj
+
+
 def build(force=False, verbose=False):
     hipcc = _hipcc()
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    objs = []
     common = ["-O3", "-std=c++17", "-fPIC", "-I" + CSRC, "-D__HIP_PLATFORM_AMD__", "-Wall",
               "-Wno-unused-function", "-Wno-unused-value"]
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    for s in SOURCES:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(HERE, "build", s.rsplit(".", 1)[0] + ".o")
-        objs.append(obj)
-        if force or _stale(obj, [src] + deps):
-            dev = ["-x", "hip", f"--offload-arch={ARCH}"] if s.endswith(".hip") else []
-            cmd = [hipcc] + common + dev + ["-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+    objs = [os.path.join(HERE, "build", s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
+    todo = [s for s, obj in zip(SOURCES, objs) if force or _stale(obj, [os.path.join(CSRC, s)] + deps)]
+    # the translation units are independent: compile them side by side (the slice-GEMM parts take minutes each)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
+        for f in [pool.submit(_compile, hipcc, common, s, verbose) for s in todo]:
+            f.result()
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:

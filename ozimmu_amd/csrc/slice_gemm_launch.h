@@ -1,0 +1,267 @@
+// slice_gemm_launch.h — host side of the slice GEMM: kernel choice, tile plan and launches of one compute mode S
+// (design notes: slice_gemm.hip).  Included by the slice_gemm_s*.hip translation units, each of which instantiates the
+// kernels of a range of S (OZ_S_LO .. OZ_S_HI) behind one entry point OZ_PART(S, args, stream): the ~60 kernel
+// instantiations compile in parallel instead of in one five-minute translation unit.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+
+#include "slice_gemm_k2_kernel.h"
+#include "slice_gemm_w_kernel.h"
+
+namespace ozhip {
+
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one bit per device id and kernel
+// instantiation (a process may drive several GPUs through one copy of this library).
+template <class K>
+static hipError_t allow_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
+static int cu_count() { // CUs of the current device (cached per device id)
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+// ---- classic kernel: 64x64 (or 128x64) workgroups, two waves per SIMD ----------------------------------------------
+template <int S, int D0, int ND, int FORCE_WM = 0>
+static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
+  constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
+  // Workgroup shape (FORCE_WM: the caller's choice, see launch_S).  Up to 10 staged slices: 4 waves / 64x64, two workgroups per CU (they cover each other's
+  // LDS-read phases).  11..13 staged slices do not fit twice in 160 KiB of LDS: one 8-wave 128x64 workgroup per CU
+  // (2*(4+2)*SL KiB).  More than 13 (second pass of S >= 14): back to 64x64, one workgroup per CU.
+  constexpr int WM = FORCE_WM ? FORCE_WM : ((SL >= 11 && SL <= 13) ? 4 : 2);
+  constexpr size_t lds = 2 * (WM + 2) * SL * FRAG_BYTES;
+  // the prefetch-2 loop keeps all 2*SL fragments in registers next to the 16*ND accumulators: beyond
+  // ~232 of the 256 VGPRs (2 waves/SIMD) it would spill inside the k loop, and with one 8-wave workgroup per CU
+  // its LDS read burst is exposed (tools/gemm_ablate.hip: 24.3 vs 19.6 ms): those cases stream the A fragments
+  // (prefetch distance 1).
+  constexpr int VAR_PRODUCTION = (WM == 2 && 16 * ND + 8 * SL <= 240) ? VAR_SHIPPED : (VAR_SHIPPED & ~VAR_PF2);
+  SliceGemmArgs a = a0;
+  a.tiles_m = (a.M + 32 * WM - 1) / (32 * WM);
+  a.tiles_n = (a.N + 63) / 64;
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>, lds, attr_done)) return e;
+  const uint32_t nb = a.tiles_m * a.tiles_n;
+  hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>), dim3(nb, a.batch > 1 ? a.batch : 1),
+                     dim3(128 * WM), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ---- K-split kernel: one 8-wave workgroup per CU, 64x64 tiles, for launches with no more tiles than CUs --------------
+template <int S, int D0, int ND>
+static hipError_t launch_k2(const SliceGemmArgs &a0, hipStream_t stream) {
+  using Cfg = K2Cfg<S, D0, ND>;
+  SliceGemmArgs a = a0;
+  a.tiles_m = (a.M + 63) / 64;
+  a.tiles_n = (a.N + 63) / 64;
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_k2_kernel<S, D0, ND>, Cfg::LDS, attr_done)) return e;
+  hipLaunchKernelGGL((slice_gemm_k2_kernel<S, D0, ND>), dim3(a.tiles_m * a.tiles_n, a.batch > 1 ? a.batch : 1), dim3(512),
+                     Cfg::LDS, stream, a);
+  return hipGetLastError();
+}
+
+// ---- wide kernel: one 4-wave workgroup per CU, (32*WA) x 128 tiles (slice_gemm_w_kernel.h) ------------------------
+// WA: as many blocks per wave as the 512-entry register file holds next to the B fragments, the ring and addressing;
+// NA: 2 A buffers = prefetch distance 1.  Distance 2 (3 buffers) is never faster and up to 6 % slower (profiles/
+// r2_ablate: 17.66 vs 18.74 ms on the slowest box, equal on the fastest): a k-step of this kernel lasts ~2.8 us, enough
+// for a copy to land, and prefetching two steps ahead widens the k window the XCD's workgroups keep alive in L2.
+template <int S, int D0, int ND>
+struct WideCfg {
+  static constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
+  static constexpr bool regs_ok(int wa) { return wa * ND * 16 + SL * 4 + 16 + 14 <= 512; }
+  static constexpr size_t lds(int wa, int na) { return (size_t)(na * wa + 8) * SL * FRAG_BYTES; }
+  static constexpr size_t LDS_MAX = 160 * 1024;
+  static constexpr int WA = (regs_ok(4) && lds(4, 2) <= LDS_MAX)   ? 4
+                            : (regs_ok(3) && lds(3, 2) <= LDS_MAX) ? 3
+                            : (regs_ok(2) && lds(2, 2) <= LDS_MAX) ? 2
+                            : (regs_ok(1) && lds(1, 2) <= LDS_MAX) ? 1 // 14..16 staged slices (second pass of S = 14..16)
+                                                                   : 0;
+  static constexpr int NA = 2;
+  static constexpr bool ok = WA >= 1;
+};
+
+// Rows of full-height (WA blocks) and reduced (WA-1 blocks) tiles that cover `rows32` 32-row blocks with the smallest
+// makespan on `ncu` CUs.  Workgroups are dispatched in order, big tiles first, each to the first CU that frees up; a
+// tile of h blocks costs h + OVH (k loop + prologue/epilogue).  Finish times take few distinct values, so the greedy
+// assignment is simulated on (time -> CU count) buckets.
+struct WidePlan {
+  uint32_t n_big = 0, n_small = 0;
+  double makespan = 0; // in block units per CU
+  double efficiency = 0;
+};
+static double simulate_rounds(uint64_t nbig, double cbig, uint64_t nsmall, double csmall, int ncu) {
+  std::map<double, uint64_t> free_at; // time -> CUs that become free then
+  free_at[0.0] = (uint64_t)ncu;
+  double last = 0;
+  auto run = [&](uint64_t n, double c) {
+    while (n) {
+      auto it = free_at.begin();
+      const uint64_t take = n < it->second ? n : it->second;
+      const double t = it->first + c;
+      it->second -= take;
+      if (it->second == 0) free_at.erase(it);
+      free_at[t] += take;
+      if (t > last) last = t;
+      n -= take;
+    }
+  };
+  run(nbig, cbig);
+  run(nsmall, csmall);
+  return last;
+}
+static WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) {
+  constexpr double OVH = 0.06;
+  const uint32_t rows32 = (M + 31) / 32, tn = (N + 127) / 128;
+  WidePlan best;
+  const uint32_t max_small = WA > 1 ? (rows32 + (WA - 2)) / (WA - 1) : 0;
+  for (uint32_t n2 = 0; n2 <= max_small; n2++) {
+    const uint32_t covered = (uint32_t)(WA - 1) * n2;
+    const uint32_t n3 = covered >= rows32 ? 0 : (rows32 - covered + WA - 1) / WA;
+    const double t = simulate_rounds((uint64_t)n3 * tn, WA + OVH, (uint64_t)n2 * tn, WA - 1 + OVH, ncu);
+    if (best.makespan == 0 || t < best.makespan - 1e-9) {
+      best.n_big = n3;
+      best.n_small = n2;
+      best.makespan = t;
+    }
+    if (n3 == 0) break;
+  }
+  if (const char *e = getenv("OZIMMU_HIP_WIDE_SMALL_ROWS")) { // measurement override: rows of reduced-height tiles
+    const uint32_t n2 = std::min<uint32_t>((uint32_t)std::atoi(e), max_small);
+    const uint32_t covered = (uint32_t)(WA - 1) * n2;
+    best.n_small = n2;
+    best.n_big = covered >= rows32 ? 0 : (rows32 - covered + WA - 1) / WA;
+    best.makespan = simulate_rounds((uint64_t)best.n_big * tn, WA + OVH, (uint64_t)n2 * tn, WA - 1 + OVH, ncu);
+  }
+  best.efficiency = (double)rows32 * tn / (best.makespan * ncu);
+  return best;
+}
+
+// The wide kernel wins once its tiles occupy about 3/4 of the CUs (measured, fp64_int8_9 square sizes, tools/
+// bench_kernel_choice.py: 1536^3 = 192 tiles: 177 vs 211 us; 2048^3 339 vs 347; 3072^3 1006 vs 1124; 8192^3 16.9 vs
+// 19.5 ms; at 1024^3 its 128 tiles of 64x128 lose to the classic kernel's 256 of 64x64: 92 vs 76 us).
+// OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements, parity tests of both kernels on small shapes).
+static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu) {
+  if (const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL")) {
+    if (!std::strcmp(e, "wide")) return true;
+    if (!std::strcmp(e, "classic")) return false;
+  }
+  const uint64_t wgs = (uint64_t)(pl.n_big + pl.n_small) * tn;
+  return 10 * wgs >= 7 * (uint64_t)ncu;
+}
+
+template <int S, int D0, int ND>
+static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipStream_t stream) {
+  using Cfg = WideCfg<S, D0, ND>;
+  constexpr int VARW = Cfg::NA == 3 ? VARW_NA3 : 0;
+  constexpr size_t lds = Cfg::lds(Cfg::WA, Cfg::NA);
+  SliceGemmArgs a = a0;
+  a.tiles_m = pl.n_big;
+  a.tiles_m2 = pl.n_small;
+  a.tiles_n = (a.N + 127) / 128;
+  a.rba = (uint32_t)row_blocks_padded(a.M);
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>, lds, attr_done)) return e;
+  uint32_t nb = (a.tiles_m + a.tiles_m2) * a.tiles_n;
+  // persistent workgroups with per-XCD tile queues + stealing when there is a zeroed counter pair for this launch
+  // (single products only: the phase lines are per call) and more tiles than CUs; OZIMMU_HIP_WIDE_STATIC=1: A/B
+  a.queue = nullptr;
+  const uint32_t max_slots = 24; // words 16 .. 63 of a phase line
+  if (a.phase && a.batch <= 1 && a.qslot < max_slots && nb > (uint32_t)cu_count() &&
+      !(getenv("OZIMMU_HIP_WIDE_STATIC") && std::atoi(getenv("OZIMMU_HIP_WIDE_STATIC")))) {
+    a.queue = a.phase + 16 + 2 * a.qslot;
+    nb = (uint32_t)cu_count();
+    if (const char *e = getenv("OZIMMU_HIP_WIDE_GRID")) nb = std::max(1, std::atoi(e)); // tests: few workgroups, many tiles each
+  } else if (getenv("OZIMMU_HIP_WIDE_GRID") && a.phase && a.batch <= 1 && a.qslot < max_slots) {
+    a.queue = a.phase + 16 + 2 * a.qslot;
+    nb = std::min<uint32_t>(nb, (uint32_t)std::max(1, std::atoi(getenv("OZIMMU_HIP_WIDE_GRID"))));
+  }
+  hipLaunchKernelGGL((slice_gemm_w_kernel<S, D0, ND, Cfg::WA, VARW>), dim3(nb, a.batch > 1 ? a.batch : 1), dim3(256), lds,
+                     stream, a);
+  return hipGetLastError();
+}
+
+// one pass over the diagonals [D0, D0 + ND): wide kernel when it fits the registers / LDS and the problem fills the
+// chip, else the classic one
+template <int S, int D0, int ND, int FORCE_WM = 0>
+static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
+  // S <= 4: few MFMAs per staged byte even on 128x128 tiles; the classic 8-wave 128x64 kernel measures faster
+  // (4096^3: S=3 241 vs 214, S=4 174 vs 168 TFLOP/s; from S=5 on the wide kernel leads by 6-13 %)
+  constexpr bool wide_pays = ND >= 5 || D0 > 0;
+  if constexpr (K2Cfg<S, D0, ND>::ok) {
+    // no more 64x64 tiles than CUs (all matrices of a batch together): the classic kernel would run one wave per SIMD;
+    // split K inside an 8-wave workgroup instead (slice_gemm_k2_kernel.h; 1024^3 S=9: 48.6 -> see DESIGN.md)
+    const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL");
+    const uint64_t wgs = (uint64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.batch > 1 ? a.batch : 1);
+    if (e ? !std::strcmp(e, "k2") : (wgs <= (uint64_t)cu_count() && a.kb1 - a.kb0 >= 4))
+      return launch_k2<S, D0, ND>(a, stream);
+  }
+  if (WideCfg<S, D0, ND>::ok && (wide_pays || getenv("OZIMMU_HIP_GEMM_KERNEL"))) {
+    const int ncu = cu_count();
+    // a strided batch fills the chip with all its matrices: plan one matrix on the CUs it gets on average
+    const uint32_t nbatch = a.batch > 1 ? a.batch : 1;
+    const int ncu_eff = (int)(ncu / nbatch) > 0 ? (int)(ncu / nbatch) : 1;
+    const WidePlan pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu_eff);
+    if constexpr (WideCfg<S, D0, ND>::ok)
+      if (prefer_wide(pl, (a.N + 127) / 128, ncu_eff)) return launch_wide<S, D0, ND>(a, pl, stream);
+  }
+  return launch_one<S, D0, ND, FORCE_WM>(a, stream);
+}
+
+// S <= SINGLE_PASS_MAX_S: all S diagonals in one pass.  Larger S: two diagonal ranges, the second pass
+// continues the first one's fma chain through the FP64 `acc` workspace (same summation order).
+template <int S>
+static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
+  if constexpr (S <= SINGLE_PASS_MAX_S) {
+    if constexpr (S <= 6) {
+      // few slices = few MFMAs per staged byte: the 128x64 8-wave workgroup (-25 % staged bytes) wins once there
+      // are enough tiles to fill the chip (4096^3: S=3 +8 %, S=4 +18 %, S=5 +10 %, S=6 +7 %; S=7 +1 %, S=8 -2 %)
+      if ((size_t)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 512) return launch_pass<S, 0, S, 4>(a, stream);
+    }
+    return launch_pass<S, 0, S>(a, stream);
+  } else {
+    constexpr int ND1 = (S + 1) / 2, ND2 = S - ND1;
+    SliceGemmArgs a1 = a;
+    a1.final = 0; // -> acc
+    hipError_t e = launch_pass<S, 0, ND1>(a1, stream);
+    if (e != hipSuccess) return e;
+    SliceGemmArgs a2 = a;
+    a2.acc_in = 1;
+    a2.qslot = a.qslot + 1; // own claim counters (the host advances qslot by 2 per call of launch_slice_gemm)
+    if (a2.dump) a2.dump += (size_t)ND1 * a.N * a.M;
+    return launch_pass<S, ND1, ND2>(a2, stream);
+  }
+}
+
+
+template <int S>
+static hipError_t dispatch_S(int s, const SliceGemmArgs &a, hipStream_t stream) {
+  if constexpr (S > OZ_S_HI) {
+    return hipErrorInvalidValue;
+  } else {
+    if (s == S) return launch_S<S>(a, stream);
+    return dispatch_S<S + 1>(s, a, stream);
+  }
+}
+
+hipError_t OZ_PART(int S, const SliceGemmArgs &a, hipStream_t stream) { return dispatch_S<OZ_S_LO>(S, a, stream); }
+
+} // namespace ozhip

@@ -5,10 +5,12 @@ that the compiler does not know about.
   the loop's own `s_waitcnt lgkmcnt(0)`: no instruction may touch that SGPR in between (a compiler-inserted copy would
   capture a stale value);
 * no slice GEMM or split kernel uses scratch (a spill inside the k loop would be a silent 2x slowdown)."""
+import concurrent.futures
 import os
 import re
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -22,15 +24,28 @@ def _hipcc():
 
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
+    """{"slice_gemm.hip": assembly of all slice-GEMM translation units, "split.hip": ...}"""
+    sys.path.insert(0, ROOT)
+    from ozimmu_amd import build as B
     d = tmp_path_factory.mktemp("isa")
-    out = {}
-    for src in ("slice_gemm.hip", "split.hip"):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+
+    def device_asm(src):
+        # the library build (python -m ozimmu_amd.build, -save-temps=obj) leaves the device assembly behind: use it if
+        # it is newer than every source, else compile
+        kept = B.device_asm_path(src)
+        if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(f) for f in deps):
+            return open(kept).read()
         o = d / (src + ".s")
         subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC,
                                "-D__HIP_PLATFORM_AMD__", "-x", "hip", "--cuda-device-only", "-S",
                                os.path.join(CSRC, src), "-o", str(o)])
-        out[src] = o.read_text()
-    return out
+        return o.read_text()
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=len(B.GEMM_PARTS) + 1) as pool:
+        parts = [pool.submit(device_asm, src) for src in B.GEMM_PARTS]
+        split = pool.submit(device_asm, "split.hip")
+        return {"slice_gemm.hip": "\n".join(f.result() for f in parts), "split.hip": split.result()}
 
 
 def test_throttle_scalar_load_is_not_touched_before_its_wait(asm):
