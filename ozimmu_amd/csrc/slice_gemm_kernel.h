@@ -1,4 +1,4 @@
-// slice_gemm_kernel.h — device code of the fused INT8 slice GEMM (see slice_gemm.hip for the design notes).
+// slice_gemm_kernel.h — device code of the fused INT8 slice GEMM (see slice_gemm.hip and slice_gemm_launch.h for the design notes).
 //
 // Kept in a header so that tools/gemm_ablate.hip can instantiate MEASUREMENT variants of the very same kernel for
 // within-process A/B timing.  The VAR template argument is a bit set: the library ships
