@@ -22,6 +22,9 @@
 // 16 + S).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include <type_traits>
 
 #include "kernels.h"
@@ -381,6 +384,9 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
 }
 
 // up to 4 operand views per launch (see row_max_kernel): the form for small problems
+// PF: the k-contiguous path prefetches along its strip (only useful for strips of more than one block; without it the
+// kernel needs ~100 instead of 186 registers, i.e. 4 instead of 2 waves per SIMD for BOTH layouts of the launch)
+template <bool PF>
 __global__ __launch_bounds__(256) void cut_multi_kernel(const SplitJobs jobs) {
   __shared__ double tiles[4][32][33];
   int ji = 0;
@@ -402,16 +408,21 @@ __global__ __launch_bounds__(256) void cut_multi_kernel(const SplitJobs jobs) {
   double *max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + off);
   const size_t RB = (j.v.rows + TILE_ROWS - 1) / TILE_ROWS * (TILE_ROWS / FRAG_ROWS), KB = (j.v.K + FRAG_K - 1) / FRAG_K;
   if (j.v.stride_k < j.v.stride_r)
-    cut_body<true, true>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp, RB,
-                         KB, (int)strip, blk, tiles);
+    cut_body<true, PF>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp, RB,
+                       KB, (int)strip, blk, tiles);
   else
     cut_body<false, false>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp,
                            RB, KB, 1, blk, tiles);
 }
 
 static int cut_strip_for(bool kcontig, size_t RB, size_t KB) {
-  // strip length: up to 4 blocks per wave as long as >= 2048 workgroups remain to fill the chip
-  return !kcontig ? 1 : (RB * KB >= 4 * 8192 ? 4 : (RB * KB >= 2 * 8192 ? 2 : 1));
+  // One block per wave in both layouts.  Strips of 2..4 blocks with a register prefetch along the strip (PREFETCH) were
+  // the faster form of the k-contiguous cut while it sat at 2 waves/SIMD; since the 32-bit field extraction the
+  // one-block form needs 108 registers (4 waves/SIMD) and wins at every size (tools/ab_split_strip.py: 4096^3 -1.6 %,
+  // 8192^3 -0.4..1 % of the call).  OZIMMU_HIP_SPLIT_STRIP=n keeps the strip form for A/B runs.
+  (void)RB, (void)KB;
+  if (const char *e = getenv("OZIMMU_HIP_SPLIT_STRIP")) return kcontig ? std::max(1, std::atoi(e)) : 1;
+  return 1;
 }
 
 hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch,
@@ -436,7 +447,12 @@ hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStr
   }
   if (total == 0 || batch == 0) return hipSuccess;
   if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(cut_multi_kernel, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+  bool prefetch = false;
+  for (int i = 0; i < count; i++) prefetch = prefetch || (jobs.nblk[i] && jobs.nx[i] > 1);
+  if (prefetch)
+    hipLaunchKernelGGL(cut_multi_kernel<true>, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+  else
+    hipLaunchKernelGGL(cut_multi_kernel<false>, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
   return hipGetLastError();
 }
 
@@ -448,7 +464,10 @@ hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, 
   const int strip = cut_strip_for(kcontig, RB, KB);
   const size_t strips = ((kcontig ? KB : RB) + strip - 1) / strip * (kcontig ? RB : KB);
   const dim3 grid((unsigned)((strips + 3) / 4), 1, b.count);
-  if (kcontig)
+  if (kcontig && strip == 1) // no strip to prefetch along: the register-lean form (4 waves per SIMD instead of 2)
+    hipLaunchKernelGGL((cut_kernel<true, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+  else if (kcontig)
     hipLaunchKernelGGL(cut_kernel<true>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
                        exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
   else

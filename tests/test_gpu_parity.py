@@ -24,6 +24,7 @@ def split_kernel(request, monkeypatch):
     if request.param == "banded_split":
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_MULTI_BYTES", "0")
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_BAND_BYTES", "65536")
+        monkeypatch.setenv("OZIMMU_HIP_SPLIT_STRIP", "3")  # the k-contiguous cut's strip + prefetch form (A/B switch)
     elif request.param == "one_pass_split":
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_ONE_PASS_BYTES", str(1 << 40))
 

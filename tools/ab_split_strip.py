@@ -1,0 +1,22 @@
+"""A/B of the k-contiguous cut's strip length (OZIMMU_HIP_SPLIT_STRIP; 1 = register-lean form without prefetch, 4 waves
+per SIMD) at several sizes: whole-call time, N/N (A row-contiguous, B k-contiguous) and T/N (both k-contiguous)."""
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+for n in [int(x) for x in sys.argv[1:]] or [2048, 4096, 8192]:
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    for ops in ("NN", "TN"):
+        def call(): assert oz.gemm(h, ops[0], ops[1], n, n, n, 1.0, a, n, b, n, 0.0, c, n, "fp64_int8_9") == 0
+        res = {}
+        reps = 40 if n <= 2048 else (10 if n <= 4096 else 4)
+        for r in range(3):
+            for strip in (None, "1", "2", "4"):
+                if strip: os.environ["OZIMMU_HIP_SPLIT_STRIP"] = strip
+                else: os.environ.pop("OZIMMU_HIP_SPLIT_STRIP", None)
+                call(); call(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps): call()
+                torch.cuda.synchronize(); res.setdefault(strip, []).append((time.perf_counter() - t0) / reps * 1e6)
+        print(f"n={n} {ops}: " + "  ".join(f"strip {k or 'default'}: {sorted(v)[1]:9.1f} us" for k, v in res.items()), flush=True)
