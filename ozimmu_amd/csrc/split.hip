@@ -243,33 +243,36 @@ __device__ __forceinline__ double max_exp_of(unsigned e) {
 }
 
 // out: this lane's 16 bytes of slice 0 inside the fragment block run (slice s follows FRAG_BYTES * s later)
+// LOW = false: the caller guarantees S * L <= 64, i.e. every slice lies in the upper two words of the 128-bit value (all
+// modes up to fp64_int8_9 at L = 7): the lower words are neither built nor kept (32 registers and a third of the selects)
+template <bool LOW = true>
 __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e, int S, int L, int8_t *out) {
   const bool live = e != 0u && e < 0x7FEu;
-  // 128-bit shifted mantissa (hi:lo) = (m53 << 75) >> off, per element (src/split.cu:163-175)
-  unsigned long long hi[16], lo[16];
+  // 128-bit shifted mantissa W = (m53 << 75) >> off per element (src/split.cu:163-175), built as four 32-bit words
+  // without branches: V = m53 << 11 (top-aligned 64 bits) is shifted right by off % 32 with funnel shifts and then moved
+  // down by off / 32 whole words with selects.  (The first form used 64-bit variable shifts under per-element
+  // `if (off < 64) ... else if (off < 128)`: exec-mask branches and quarter-rate shifts, a third of the kernel's VALU time.)
+  constexpr int NW = LOW ? 4 : 2; // words kept: the top NW of the four; W[q][i] = word 4 - NW + i
+  unsigned W[16][NW];
   unsigned negmask[4] = {0, 0, 0, 0}; // per packed word: 0xFF in the bytes of negative elements
 #pragma unroll
   for (int q = 0; q < 16; q++) {
     const unsigned long long bq = (unsigned long long)__double_as_longlong(v[q]);
-    const unsigned f = (unsigned)(bq >> 52) & 0x7FFu;
-    const unsigned long long m53 = (bq & MANT_MASK) | (f ? (1ull << 52) : 0ull);
+    const unsigned bh = (unsigned)(bq >> 32), bl = (unsigned)bq;
+    const unsigned f = (bh >> 20) & 0x7FFu;
+    const unsigned mh = (bh & 0xFFFFFu) | (f ? 0x100000u : 0u); // m53 = (mh:bl), 21 + 32 bits
     const unsigned ef = f ? f : 1u; // subnormal: exponent of field 1 (fix of SURVEY §8a quirk 7)
     const unsigned off = e + 1u - ef; // >= 1 for live rows
-    const unsigned long long V = live ? (m53 << 11) : 0ull;
-    unsigned long long h, l;
-    if (off < 64u) {
-      h = V >> off;
-      l = V << (64u - off); // off >= 1
-    } else if (off < 128u) {
-      h = 0;
-      l = V >> (off - 64u);
-    } else {
-      h = 0;
-      l = 0;
+    const unsigned vh = live ? ((mh << 11) | (bl >> 21)) : 0u, vl = live ? (bl << 11) : 0u; // V = m53 << 11
+    const unsigned wa = off >> 5, wb = off & 31u;
+    const unsigned t3 = vh >> wb, t2 = __builtin_amdgcn_alignbit(vh, vl, wb), t1 = __builtin_amdgcn_alignbit(vl, 0u, wb);
+    W[q][NW - 1] = wa == 0u ? t3 : 0u;
+    W[q][NW - 2] = wa == 0u ? t2 : wa == 1u ? t3 : 0u;
+    if constexpr (LOW) {
+      W[q][1] = wa == 0u ? t1 : wa == 1u ? t2 : wa == 2u ? t3 : 0u;
+      W[q][0] = wa == 1u ? t1 : wa == 2u ? t2 : wa == 3u ? t3 : 0u;
     }
-    hi[q] = h;
-    lo[q] = l;
-    if (bq >> 63) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
+    if (bh >> 31) negmask[q >> 2] |= 0xFFu << (8 * (q & 3)); // sign_flag = a > 0 (src/split.cu:159)
   }
 
   // Slice s = bits [p, p + L) of the 128-bit value, p = 128 - (s + 1) * L >= 2.  The kernel is VALU bound (rocprofv3:
@@ -279,7 +282,7 @@ __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e,
   // v_and (across two words), plus one v_lshl_or_b32 to place its byte.
   const unsigned mask = (1u << L) - 1u;
   auto word = [&](int q, int i) -> unsigned { // word i (0 = least significant) of element q's 128-bit value
-    return i >= 4 ? 0u : i == 3 ? (unsigned)(hi[q] >> 32) : i == 2 ? (unsigned)hi[q] : i == 1 ? (unsigned)(lo[q] >> 32) : (unsigned)lo[q];
+    return (i >= 4 || i < 4 - NW) ? 0u : W[q][(i >= 4 || i < 4 - NW) ? 0 : i - (4 - NW)];
   };
   for (int s = 0; s < S; s++) {
     const int p = 128 - (s + 1) * L;
@@ -296,11 +299,16 @@ __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e,
           w[q >> 2] |= (__builtin_amdgcn_alignbit(word(q, WI + 1), word(q, WI), (unsigned)r) & mask) << (8 * (q & 3));
       }
     };
-    switch (wi) { // wave-uniform
-      case 3: extract(std::integral_constant<int, 3>{}); break;
-      case 2: extract(std::integral_constant<int, 2>{}); break;
-      case 1: extract(std::integral_constant<int, 1>{}); break;
-      default: extract(std::integral_constant<int, 0>{}); break;
+    if constexpr (LOW) {
+      switch (wi) { // wave-uniform
+        case 3: extract(std::integral_constant<int, 3>{}); break;
+        case 2: extract(std::integral_constant<int, 2>{}); break;
+        case 1: extract(std::integral_constant<int, 1>{}); break;
+        default: extract(std::integral_constant<int, 0>{}); break;
+      }
+    } else {
+      if (wi == 3) extract(std::integral_constant<int, 3>{});
+      else extract(std::integral_constant<int, 2>{}); // p >= 64 by the caller's guarantee
     }
     uint4 o;
     unsigned *op = &o.x;
@@ -319,7 +327,7 @@ __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e,
 // (PREFETCH): the loads of the next block are issued before the current one is cut -- with the LDS transpose the
 // kernel sits at 2 waves/SIMD, too few to hide HBM latency by occupancy alone (8192^2: 0.53 -> 0.31 ms).
 // Row-contiguous operands keep one block per wave at 3 waves/SIMD (prefetching there only costs registers).
-template <bool KCONTIG, bool PREFETCH = KCONTIG>
+template <bool KCONTIG, bool PREFETCH = KCONTIG, bool LOW = true>
 __device__ __forceinline__ void cut_body(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
                                          const uint32_t *__restrict__ exps, int S, int L, int8_t *__restrict__ planes,
                                          double *__restrict__ max_exp, size_t RB, size_t KB, int strip, size_t block,
@@ -363,13 +371,13 @@ __device__ __forceinline__ void cut_body(const double *__restrict__ in, size_t r
     const size_t rg = rb * 32 + r;
     const unsigned e = rg < rows ? exps[rg] : 0u;
     if (kb == 0 && lane < 32 && rg < rows) max_exp[rg] = max_exp_of(e);
-    cut_and_store(v, e, S, L, planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16);
+    cut_and_store<LOW>(v, e, S, L, planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16);
   }
 }
 
 // one operand view per launch: each layout gets its own register budget (k-contiguous: 2 waves/SIMD with the LDS
 // transpose and prefetch; row-contiguous: 3 waves/SIMD) -- the form for operands that are bandwidth bound
-template <bool KCONTIG, bool PREFETCH = KCONTIG>
+template <bool KCONTIG, bool PREFETCH = KCONTIG, bool LOW = true>
 __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in, size_t rows, size_t K,
                                                   size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
                                                   int8_t *__restrict__ planes, double *__restrict__ max_exp,
@@ -380,13 +388,13 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
   exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(exps) + (size_t)blockIdx.z * ws_stride);
   planes += (size_t)blockIdx.z * ws_stride;
   max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(max_exp) + (size_t)blockIdx.z * ws_stride);
-  cut_body<KCONTIG, PREFETCH>(in, rows, K, sr, sk, exps, S, L, planes, max_exp, RB, KB, strip, blockIdx.x, tiles);
+  cut_body<KCONTIG, PREFETCH, LOW>(in, rows, K, sr, sk, exps, S, L, planes, max_exp, RB, KB, strip, blockIdx.x, tiles);
 }
 
 // up to 4 operand views per launch (see row_max_kernel): the form for small problems
 // PF: the k-contiguous path prefetches along its strip (only useful for strips of more than one block; without it the
 // kernel needs ~100 instead of 186 registers, i.e. 4 instead of 2 waves per SIMD for BOTH layouts of the launch)
-template <bool PF>
+template <bool PF, bool LOW = true>
 __global__ __launch_bounds__(256) void cut_multi_kernel(const SplitJobs jobs) {
   __shared__ double tiles[4][32][33];
   int ji = 0;
@@ -408,10 +416,10 @@ __global__ __launch_bounds__(256) void cut_multi_kernel(const SplitJobs jobs) {
   double *max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + off);
   const size_t RB = (j.v.rows + TILE_ROWS - 1) / TILE_ROWS * (TILE_ROWS / FRAG_ROWS), KB = (j.v.K + FRAG_K - 1) / FRAG_K;
   if (j.v.stride_k < j.v.stride_r)
-    cut_body<true, PF>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp, RB,
+    cut_body<true, PF, LOW>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp, RB,
                        KB, (int)strip, blk, tiles);
   else
-    cut_body<false, false>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp,
+    cut_body<false, false, LOW>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp,
                            RB, KB, 1, blk, tiles);
 }
 
@@ -451,8 +459,10 @@ hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStr
   for (int i = 0; i < count; i++) prefetch = prefetch || (jobs.nblk[i] && jobs.nx[i] > 1);
   if (prefetch)
     hipLaunchKernelGGL(cut_multi_kernel<true>, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
-  else
-    hipLaunchKernelGGL(cut_multi_kernel<false>, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+  else if (S * L > 64)
+    hipLaunchKernelGGL((cut_multi_kernel<false, true>), dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+  else // every slice in the upper 64 bits of the shifted mantissa (up to fp64_int8_9 at L = 7): the lean form
+    hipLaunchKernelGGL((cut_multi_kernel<false, false>), dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
   return hipGetLastError();
 }
 
@@ -464,14 +474,21 @@ hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, 
   const int strip = cut_strip_for(kcontig, RB, KB);
   const size_t strips = ((kcontig ? KB : RB) + strip - 1) / strip * (kcontig ? RB : KB);
   const dim3 grid((unsigned)((strips + 3) / 4), 1, b.count);
-  if (kcontig && strip == 1) // no strip to prefetch along: the register-lean form (4 waves per SIMD instead of 2)
-    hipLaunchKernelGGL((cut_kernel<true, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
+  const bool low = S * L > 64; // some slice reaches into the lower 64 bits of the shifted mantissa
+  if (kcontig && strip == 1 && low) // no strip to prefetch along: the register-lean form (4 waves per SIMD instead of 2)
+    hipLaunchKernelGGL((cut_kernel<true, false, true>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+  else if (kcontig && strip == 1)
+    hipLaunchKernelGGL((cut_kernel<true, false, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
                        exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
   else if (kcontig)
     hipLaunchKernelGGL(cut_kernel<true>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
                        exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+  else if (low)
+    hipLaunchKernelGGL((cut_kernel<false, false, true>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
   else
-    hipLaunchKernelGGL(cut_kernel<false>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
+    hipLaunchKernelGGL((cut_kernel<false, false, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
                        exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
   return hipGetLastError();
 }
