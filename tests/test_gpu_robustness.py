@@ -358,3 +358,31 @@ def test_gemm_is_capturable_into_a_graph_once_the_workspace_exists(oz):
     finally:
         torch.cuda.synchronize()
         m_.destroy(h)
+
+
+@pytest.mark.parametrize("m,n,k,op_a,op_b", [
+    (60000, 40, 50, "N", "N"),    # tall and skinny: ~1900 row tiles, one column tile
+    (33, 50000, 70, "T", "N"),    # short and wide
+    (70, 90, 40000, "N", "T"),    # deep: three chained K chunks at S = 9
+    (5000, 3, 1000, "T", "T"),    # n below every tile width
+    (1, 4097, 129, "N", "N"),     # a single row
+])
+def test_extreme_aspect_ratios_bit_exact(oz, m, n, k, op_a, op_b):
+    """shapes far from square: tile grids with one row or one column of tiles, row counts that leave most of a tile
+    empty, K deep enough for chunked passes; whatever kernel the library picks, the bits are the oracle's"""
+    import torch
+    _, h = oz
+    S = 9
+    rng = np.random.default_rng(m + 3 * n + 7 * k)
+    a = operand(op_a, m, k, rng)
+    b = operand(op_b, k, n, rng)
+    c = ColMajor(m, n, fill=uniform_pm1, rng=rng)
+    c_ref = ColMajor(m, n)
+    c_ref.buf[...] = c.buf
+    assert ozimmu_amd.gemm(h, op_a, op_b, m, n, k, -1.25, a.dev, a.ld, b.dev, b.ld, 0.5, c.dev, c.ld, f"fp64_int8_{S}") == 0
+    torch.cuda.synchronize()
+    L = O.bits_per_int8(k)
+    kchunk = (2147483647 // (S * ((1 << L) - 1) ** 2)) // 32 * 32
+    assert O.gemm(op_a, op_b, m, n, k, -1.25, a.view, b.view, 0.5, c_ref.view, S, O.ORDER_DIAGONAL,
+                  kchunk=kchunk if k > kchunk else 0) == 0
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
