@@ -217,25 +217,31 @@ static bool zero_slot_heads(ozimmu_hip_handle_t h, void *base, size_t head_bytes
 }
 
 // Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
-// Consecutive calls on one stream are ordered by the stream.  When a call arrives on a DIFFERENT stream than the
-// previous one, the event is recorded on the previous stream at that moment (it then covers everything the earlier
-// call enqueued) and the new stream waits for it: no event per call - a recorded event costs every call ~6 us of
-// dispatch gap in front of its first kernel (rocprofv3 kernel trace, 1024^3), a tenth of a small GEMM.  If the earlier
-// stream no longer exists (hipEventRecord rejects it) the device is synchronised instead.
+// Calls on one stream are ordered by the stream.  As long as a handle has only ever seen ONE stream (the common case: a
+// BLAS handle bound to a stream, PyTorch's current stream) nothing else is done: an event recorded after every call
+// costs each call ~6 us of dispatch gap in front of its first kernel (rocprofv3 kernel trace, 1024^3), a tenth of a
+// small GEMM.  The first time a call arrives on a different stream than its predecessor the device is synchronised
+// once (no event of the earlier call exists, and its stream may be gone by now: hipEventRecord on a destroyed stream
+// crashes inside the runtime, tests/test_gpu_robustness.py), and from then on every call records an event on its own
+// stream when it ends and a call on another stream waits for it.
 struct WorkspaceUse {
   ozimmu_hip_handle_t h;
   explicit WorkspaceUse(ozimmu_hip_handle_t handle) : h(handle) {
-    if (h->tail_valid && h->tail_stream != h->stream && !getenv("OZIMMU_HIP_TEST_NO_STREAM_ORDER")) {
-      if (h->tail_ev && hipEventRecord(h->tail_ev, h->tail_stream) == hipSuccess &&
-          hipStreamWaitEvent(h->stream, h->tail_ev, 0) == hipSuccess)
-        return;
-      (void)hipGetLastError();
-      hipDeviceSynchronize();
+    if (h->tail_stream_known && h->tail_stream != h->stream && !getenv("OZIMMU_HIP_TEST_NO_STREAM_ORDER")) {
+      if (h->multi_stream && h->tail_valid) {
+        hipStreamWaitEvent(h->stream, h->tail_ev, 0);
+      } else {
+        hipDeviceSynchronize();
+        (void)hipGetLastError();
+        h->multi_stream = true;
+      }
     }
   }
   ~WorkspaceUse() {
+    h->tail_valid = h->multi_stream && h->tail_ev && hipEventRecord(h->tail_ev, h->stream) == hipSuccess;
+    if (h->multi_stream && !h->tail_valid) (void)hipGetLastError();
     h->tail_stream = h->stream;
-    h->tail_valid = true;
+    h->tail_stream_known = true;
   }
 };
 

@@ -40,7 +40,9 @@ struct ozimmu_hip_handle {
   // waits for the last user of the workspace (the reference would let the two streams race on it)
   hipEvent_t tail_ev = nullptr;
   hipStream_t tail_stream = nullptr;
-  bool tail_valid = false;
+  bool tail_valid = false;        // tail_ev was recorded at the end of the previous call
+  bool tail_stream_known = false; // a previous call exists (tail_stream is its stream)
+  bool multi_stream = false;      // this handle has seen calls on more than one stream: record an event per call
 
   // private vendor BLAS handle for the `dgemm` mode (src/handle.hpp:8), created lazily
   void *rocblas_handle = nullptr;

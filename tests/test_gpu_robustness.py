@@ -386,3 +386,34 @@ def test_extreme_aspect_ratios_bit_exact(oz, m, n, k, op_a, op_b):
     assert O.gemm(op_a, op_b, m, n, k, -1.25, a.view, b.view, 0.5, c_ref.view, S, O.ORDER_DIAGONAL,
                   kchunk=kchunk if k > kchunk else 0) == 0
     np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
+def test_call_after_the_previous_calls_stream_was_destroyed(oz):
+    """cross-stream ordering records its event lazily, on the PREVIOUS call's stream at the moment a call arrives on a
+    different one; if the application has destroyed that stream in the meantime, the record is rejected and the library
+    synchronises the device instead of touching a dead handle"""
+    import torch
+    m_, h = oz
+    hip = ctypes.CDLL("libamdhip64.so.7")  # the runtime torch and the library already share (same soname)
+    m, n, k, S = 200, 150, 96, 9
+    rng = np.random.default_rng(123)
+    a = operand("N", m, k, rng)
+    b = operand("N", k, n, rng)
+    c_ref = ColMajor(m, n)
+    assert O.gemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    a.dev, b.dev
+    torch.cuda.synchronize()
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+    c1 = torch.zeros(n, m, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert m_.gemm_on_stream(h, raw.value, "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c1, m, f"fp64_int8_{S}") == 0
+    assert hip.hipStreamSynchronize(raw) == 0
+    assert hip.hipStreamDestroy(raw) == 0
+    c2 = torch.zeros(n, m, dtype=torch.float64, device="cuda")
+    st = m_.gemm_on_stream(h, torch.cuda.current_stream(), "N", "N", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c2, m,
+                           f"fp64_int8_{S}")
+    torch.cuda.synchronize()
+    assert st == 0
+    for c in (c1, c2):
+        np.testing.assert_array_equal(c.cpu().numpy().view(np.uint64), c_ref.buf.view(np.uint64))
