@@ -12,7 +12,8 @@ bound = {6: 1e-8, 8: 1e-12, 9: 1e-13, 10: 1e-13, 11: 1e-13, 13: 1e-13, 16: 1e-13
 worst = 0.0
 t0 = time.time()
 for it in range(iters):
-    lo, hi = (1024, 3000) if it % 3 else (2900, 6200)   # every third case is big enough for the lead throttle
+    # a third of the cases big enough for the lead throttle, a third small enough for the K-split kernel (<= 1 tile per CU)
+    lo, hi = ((2900, 6200), (1024, 3000), (200, 1100))[it % 3]
     m, n = (int(rng.integers(lo, hi)) for _ in range(2))
     k = int(rng.choice([1024, 2000, 4097, 6144, 9000, 15000]))
     S = int(rng.choice(list(bound)))
