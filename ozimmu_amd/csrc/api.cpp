@@ -464,8 +464,11 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   int launches = 0;
 
   static const int order[4][2] = {{1, 1}, {0, 0}, {1, 0}, {0, 1}}; // src/gemm.cu:479-480
-  for (const auto &pq : order) {
-    SliceGemmArgs g{};
+  SliceGemmArgs prod[4];
+  for (int q = 0; q < 4; q++) {
+    const int *pq = order[q];
+    SliceGemmArgs &g = prod[q];
+    g = SliceGemmArgs{};
     g.a_planes = w.planes_a[pq[0]];
     g.b_planes = w.planes_b[pq[1]];
     g.KB = (uint32_t)k_blocks(k);
@@ -493,7 +496,32 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     g.batch = (uint32_t)bs.count;
     g.ws_stride = slot;
     g.c_stride = bs.stride_c;
-    const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
+  }
+  const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K);
+  bool fused = false;
+  if (prod[0].KB <= kb_per_pass && !getenv("OZIMMU_HIP_TEST_FAIL_LAUNCH")) {
+    // one K chunk: the four products may run as ONE launch when the K-split kernel applies (small problems: three launch
+    // and drain rounds less); same order of updates per element of C.  (The fault-injection test addresses launches by
+    // number and keeps the one-by-one form.)
+    for (SliceGemmArgs &g : prod) {
+      g.kb0 = 0;
+      g.kb1 = g.KB;
+      g.acc_in = 0;
+      g.final = 1;
+    }
+    const hipError_t fe = launch_slice_gemm_fused(S, prod, 4, h->stream);
+    if (fe == hipSuccess) {
+      fused = true;
+      launches = 4;
+    } else if (fe != hipErrorNotSupported) {
+      (void)hip_ok(fe, "slice_gemm");
+      return 4;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  for (int q = 0; q < 4 && !fused; q++) {
+    SliceGemmArgs &g = prod[q];
     for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
       g.kb0 = kb0;
       g.kb1 = std::min(g.KB, kb0 + kb_per_pass);

@@ -53,6 +53,14 @@ struct Batch {
 };
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);
+// Up to four slice GEMMs that accumulate into the same C in the given order (the real products of a ZGEMM), each of them
+// a single launch (one diagonal pass, one K chunk).  One fused launch when the K-split kernel applies (at most one 64x64
+// tile per CU over all matrices); hipErrorNotSupported otherwise: the caller launches them one by one.
+struct SliceGemmMulti {
+  SliceGemmArgs g[4];
+  int count;
+};
+hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
 
 // C(complex, m x n, ldc) *= beta  (beta == 0: C = 0 without reading it); init_c_complex, src/gemm.cu:199-239
 hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, double beta_re, double beta_im,

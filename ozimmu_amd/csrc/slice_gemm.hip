@@ -61,6 +61,15 @@ hipError_t launch_slice_gemm_s9_11(int S, const SliceGemmArgs &a, hipStream_t st
 hipError_t launch_slice_gemm_s12_14(int S, const SliceGemmArgs &a, hipStream_t stream);
 hipError_t launch_slice_gemm_s15_18(int S, const SliceGemmArgs &a, hipStream_t stream);
 
+hipError_t launch_slice_gemm_fused_s3_8(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s9_11(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+
+hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g, int count, hipStream_t stream) {
+  if (S >= 3 && S <= 8) return launch_slice_gemm_fused_s3_8(S, g, count, stream);
+  if (S >= 9 && S <= 11) return launch_slice_gemm_fused_s9_11(S, g, count, stream);
+  return hipErrorNotSupported; // two diagonal passes per product, or no K-split kernel for this S
+}
+
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream) {
   if (S >= 3 && S <= 8) return launch_slice_gemm_s3_8(S, a, stream);
   if (S >= 9 && S <= 11) return launch_slice_gemm_s9_11(S, a, stream);

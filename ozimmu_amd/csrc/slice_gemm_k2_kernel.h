@@ -29,14 +29,12 @@ struct K2Cfg {
   static constexpr bool ok = LDS <= 160 * 1024 && 16 * ND + 8 * SL <= 224;
 };
 
+// one 64x64 tile (picked by blockIdx.x) of the product described by p
 template <int S, int D0, int ND>
-__global__ __launch_bounds__(512, 1) void slice_gemm_k2_kernel(const SliceGemmArgs p_in) {
-  const SliceGemmArgs p = batch_view(p_in);
+__device__ __forceinline__ void k2_tile(const SliceGemmArgs &p, char *smem) {
   using Cfg = K2Cfg<S, D0, ND>;
   constexpr int SL = Cfg::SL;
   constexpr int STAGE = (int)Cfg::STAGE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   const int lane = threadIdx.x & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave8 >> 2, wave = wave8 & 3;
@@ -170,7 +168,7 @@ __global__ __launch_bounds__(512, 1) void slice_gemm_k2_kernel(const SliceGemmAr
         *(v4i *)(red + (d * 4 + q) * 1024) = v4i{acc[d][4 * q], acc[d][4 * q + 1], acc[d][4 * q + 2], acc[d][4 * q + 3]};
   }
   __syncthreads();
-  if (grp) return;
+  if (grp) return; // (the fused-products kernel meets group 0 again at its next barrier)
 #pragma unroll
   for (int d = 0; d < ND; d++)
 #pragma unroll
@@ -182,6 +180,28 @@ __global__ __launch_bounds__(512, 1) void slice_gemm_k2_kernel(const SliceGemmAr
 
   recombine_and_store<D0, ND, 1>(p, [&](int, int d, int r) { return acc[d][r]; }, tm * 64 + wm * 32 + (lane & 31),
                                  tn * 64 + wn * 32 + 4 * (lane >> 5));
+}
+
+template <int S, int D0, int ND>
+__global__ __launch_bounds__(512, 1) void slice_gemm_k2_kernel(const SliceGemmArgs p_in) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const SliceGemmArgs p = batch_view(p_in);
+  k2_tile<S, D0, ND>(p, smem);
+}
+
+// Up to four products that accumulate into the same C one after the other -- the real products (Im,Im) (Re,Re) (Im,Re)
+// (Re,Im) of a ZGEMM -- in ONE launch: a workgroup runs its tile of every product in the given order, so each element
+// of C sees the same sequence of updates as with four launches (bit-identical), and a small ZGEMM saves three launch /
+// ramp-up / drain rounds of a ~45 us kernel.
+template <int S, int D0, int ND>
+__global__ __launch_bounds__(512, 1) void slice_gemm_k2_fused_kernel(const SliceGemmMulti m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#pragma unroll 1
+  for (int i = 0; i < m.count; i++) {
+    __syncthreads(); // group 0 is done with the previous product's LDS (accumulator hand-over) and its epilogue
+    const SliceGemmArgs p = batch_view(m.g[i]);
+    k2_tile<S, D0, ND>(p, smem);
+  }
 }
 
 } // namespace ozhip

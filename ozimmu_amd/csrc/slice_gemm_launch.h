@@ -28,6 +28,11 @@ static hipError_t allow_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t
   return e;
 }
 
+static bool env_off(const char *name) { // "0" switches a default-on feature off (A/B runs)
+  const char *e = getenv(name);
+  return e && e[0] == '0';
+}
+
 static int cu_count() { // CUs of the current device (cached per device id)
   static std::atomic<int> cached[64];
   int dev = 0;
@@ -77,6 +82,34 @@ static hipError_t launch_k2(const SliceGemmArgs &a0, hipStream_t stream) {
   hipLaunchKernelGGL((slice_gemm_k2_kernel<S, D0, ND>), dim3(a.tiles_m * a.tiles_n, a.batch > 1 ? a.batch : 1), dim3(512),
                      Cfg::LDS, stream, a);
   return hipGetLastError();
+}
+
+template <int S>
+static hipError_t launch_k2_fused(const SliceGemmArgs *g, int count, hipStream_t stream) {
+  if constexpr (S > SINGLE_PASS_MAX_S || !K2Cfg<S, 0, S>::ok) {
+    return hipErrorNotSupported;
+  } else {
+    using Cfg = K2Cfg<S, 0, S>;
+    const SliceGemmArgs &a0 = g[0];
+    const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL");
+    const uint64_t wgs = (uint64_t)((a0.M + 63) / 64) * ((a0.N + 63) / 64) * (a0.batch > 1 ? a0.batch : 1);
+    if (count < 2 || count > 4 || env_off("OZIMMU_HIP_FUSED_PRODUCTS")) return hipErrorNotSupported;
+    if (!(e ? !std::strcmp(e, "k2") : (wgs <= (uint64_t)cu_count() && a0.kb1 - a0.kb0 >= 4))) return hipErrorNotSupported;
+    SliceGemmMulti m{};
+    m.count = count;
+    for (int i = 0; i < count; i++) {
+      m.g[i] = g[i];
+      m.g[i].tiles_m = (g[i].M + 63) / 64;
+      m.g[i].tiles_n = (g[i].N + 63) / 64;
+      if (g[i].M != a0.M || g[i].N != a0.N || g[i].batch != a0.batch || g[i].kb0 != a0.kb0 || g[i].kb1 != a0.kb1)
+        return hipErrorNotSupported;
+    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (hipError_t err = allow_dynamic_lds(slice_gemm_k2_fused_kernel<S, 0, S>, Cfg::LDS, attr_done)) return err;
+    hipLaunchKernelGGL((slice_gemm_k2_fused_kernel<S, 0, S>), dim3(m.g[0].tiles_m * m.g[0].tiles_n, a0.batch > 1 ? a0.batch : 1),
+                       dim3(512), Cfg::LDS, stream, m);
+    return hipGetLastError();
+  }
 }
 
 // ---- wide kernel: one 4-wave workgroup per CU, (32*WA) x 128 tiles (slice_gemm_w_kernel.h) ------------------------
@@ -263,5 +296,19 @@ static hipError_t dispatch_S(int s, const SliceGemmArgs &a, hipStream_t stream) 
 }
 
 hipError_t OZ_PART(int S, const SliceGemmArgs &a, hipStream_t stream) { return dispatch_S<OZ_S_LO>(S, a, stream); }
+
+template <int S>
+static hipError_t dispatch_fused_S(int s, const SliceGemmArgs *g, int count, hipStream_t stream) {
+  if constexpr (S > OZ_S_HI) {
+    return hipErrorNotSupported;
+  } else {
+    if (s == S) return launch_k2_fused<S>(g, count, stream);
+    return dispatch_fused_S<S + 1>(s, g, count, stream);
+  }
+}
+
+hipError_t OZ_PART_FUSED(int S, const SliceGemmArgs *g, int count, hipStream_t stream) {
+  return dispatch_fused_S<OZ_S_LO>(S, g, count, stream);
+}
 
 } // namespace ozhip

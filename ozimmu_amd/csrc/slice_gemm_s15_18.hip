@@ -2,4 +2,5 @@
 #define OZ_S_LO 15
 #define OZ_S_HI 18
 #define OZ_PART launch_slice_gemm_s15_18
+#define OZ_PART_FUSED launch_slice_gemm_fused_s15_18
 #include "slice_gemm_launch.h"

@@ -2,4 +2,5 @@
 #define OZ_S_LO 3
 #define OZ_S_HI 8
 #define OZ_PART launch_slice_gemm_s3_8
+#define OZ_PART_FUSED launch_slice_gemm_fused_s3_8
 #include "slice_gemm_launch.h"

@@ -2,4 +2,5 @@
 #define OZ_S_LO 9
 #define OZ_S_HI 11
 #define OZ_PART launch_slice_gemm_s9_11
+#define OZ_PART_FUSED launch_slice_gemm_fused_s9_11
 #include "slice_gemm_launch.h"
