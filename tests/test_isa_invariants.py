@@ -28,7 +28,7 @@ def asm(tmp_path_factory):
     sys.path.insert(0, ROOT)
     from ozimmu_amd import build as B
     d = tmp_path_factory.mktemp("isa")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]  # what a .hip can include
 
     def device_asm(src):
         # the library build (python -m ozimmu_amd.build, -save-temps=obj) leaves the device assembly behind: use it if
