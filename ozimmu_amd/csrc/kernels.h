@@ -94,6 +94,7 @@ struct SplitJobs {
   SplitJob job[4];
   uint32_t nblk[4]; // workgroups of each view in this launch
   uint32_t nx[4];   // row_max: row groups per view (block = k chunk * nx + row group); cut: strip length
+  uint32_t kchunk[4]; // row_max: k values per workgroup
   int count, S, L;
   size_t ws_stride;
 };

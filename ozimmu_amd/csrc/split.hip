@@ -122,17 +122,17 @@ __global__ __launch_bounds__(256) void row_max_kernel(const SplitJobs jobs) {
       ji++;
     }
   SplitJob j = jobs.job[0];
-  uint32_t nx = jobs.nx[0];
-  if (ji == 1) j = jobs.job[1], nx = jobs.nx[1];
-  if (ji == 2) j = jobs.job[2], nx = jobs.nx[2];
-  if (ji == 3) j = jobs.job[3], nx = jobs.nx[3];
+  uint32_t nx = jobs.nx[0], kchunk = jobs.kchunk[0];
+  if (ji == 1) j = jobs.job[1], nx = jobs.nx[1], kchunk = jobs.kchunk[1];
+  if (ji == 2) j = jobs.job[2], nx = jobs.nx[2], kchunk = jobs.kchunk[2];
+  if (ji == 3) j = jobs.job[3], nx = jobs.nx[3], kchunk = jobs.kchunk[3];
   const double *in = j.v.in + (long long)blockIdx.z * j.in_stride;
   uint32_t *exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(j.exps) + (size_t)blockIdx.z * jobs.ws_stride);
   const uint32_t bx = blk % nx, by = blk / nx;
   if (j.v.stride_k < j.v.stride_r)
-    row_max_kcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, 8192u, bx, by);
+    row_max_kcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, kchunk, bx, by);
   else
-    row_max_rcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, 512u, bx, by, red);
+    row_max_rcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, kchunk, bx, by, red);
 }
 
 hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stream, uint32_t batch, size_t ws_stride) {
@@ -145,8 +145,13 @@ hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stre
     const OperandView &v = job[i].v;
     jobs.job[i] = job[i];
     const bool kc = v.stride_k < v.stride_r;
-    const unsigned kchunk = kc ? 8192u : 512u;
     jobs.nx[i] = (uint32_t)(kc ? (v.rows + 3) / 4 : (v.rows + 63) / 64);
+    // k values per workgroup: 8192 (one wave per row) / 512 (64 rows per workgroup) for operands that fill the chip;
+    // small operands get shorter chunks until ~1024 workgroups exist (1024 x 1024 row-contiguous: 32 -> 256 workgroups)
+    unsigned kchunk = kc ? 8192u : 512u;
+    const unsigned min_chunk = kc ? 1024u : 64u;
+    while (kchunk > min_chunk && (uint64_t)jobs.nx[i] * ((v.K + kchunk - 1) / kchunk) * batch < 1024u) kchunk /= 2;
+    jobs.kchunk[i] = kchunk;
     jobs.nblk[i] = (v.rows && v.K) ? jobs.nx[i] * (uint32_t)((v.K + kchunk - 1) / kchunk) : 0;
     if (jobs.nx[i] == 0) jobs.nx[i] = 1;
     total += jobs.nblk[i];
