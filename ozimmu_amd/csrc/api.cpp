@@ -68,12 +68,10 @@ static size_t max_k_per_pass(int S, int L) {
 }
 
 struct Workspace {
-  uint32_t *exps_a, *exps_b;
   double *ea, *eb;
   int8_t *planes_a, *planes_b;
   double *acc;
   uint32_t *phase;
-  size_t exps_bytes;
   size_t total;
 };
 
@@ -85,10 +83,7 @@ static Workspace carve(void *base, size_t m, size_t n, size_t k, int S, bool nee
     off += align256(bytes);
     return p;
   };
-  w.exps_a = (uint32_t *)take(4 * m);
-  w.exps_b = (uint32_t *)take(4 * n);
   w.phase = (uint32_t *)take(8 * 256); // one 256-byte line per XCD
-  w.exps_bytes = off; // exps_a, exps_b and phase are adjacent: one memset
   w.ea = (double *)take(8 * m);
   w.eb = (double *)take(8 * n);
   w.planes_a = (int8_t *)take(tiled_plane_bytes(m, k, S));
@@ -211,9 +206,60 @@ struct BatchSpec {
   long long stride_a = 0, stride_b = 0, stride_c = 0;
 };
 
-// zero the exponent words (and phase hints) at the head of `count` workspace slots
-static bool zero_slot_heads(ozimmu_hip_handle_t h, void *base, size_t head_bytes, size_t slot_bytes, size_t count) {
-  return hip_ok(launch_zero_words(base, head_bytes, slot_bytes, (uint32_t)count, h->stream), "zero_words");
+static bool stream_is_capturing(hipStream_t stream);
+
+// Row exponent words of one call (kernels.h: SplitJobs::tag): `parts` views of A (m rows) and of B (n rows) per matrix,
+// `count` matrices, in the handle's dedicated buffer.  The buffer only ever holds words tagged with the epoch of the call
+// that wrote them and the epoch grows with every call, so nothing is zeroed per call: once when the buffer is (re)allocated
+// and once every 2^21 calls when the epoch wraps.
+struct ExpWords {
+  uint32_t *a[2] = {nullptr, nullptr}, *b[2] = {nullptr, nullptr};
+  size_t pitch = 0; // bytes per matrix
+  uint32_t tag = 0;
+};
+static bool exp_words(ozimmu_hip_handle_t h, size_t m, size_t n, int parts, size_t count, ExpWords &x) {
+  const size_t ea = align256(4 * m), eb = align256(4 * n);
+  x.pitch = (size_t)parts * (ea + eb);
+  const size_t bytes = x.pitch * std::max<size_t>(count, 1);
+  if (bytes > h->exp_words_bytes) {
+    if (stream_is_capturing(h->stream)) return false; // allocation is illegal while the stream is captured into a graph
+    if (h->exp_words) hipFree(h->exp_words);          // device-synchronising: earlier calls are done with it
+    h->exp_words = nullptr;
+    h->exp_words_bytes = 0;
+    const size_t cap = std::max<size_t>(bytes, (size_t)1 << 20);
+    if (!hip_ok(hipMalloc((void **)&h->exp_words, cap), "exponent words") || !hip_ok(hipMemset(h->exp_words, 0, cap), "memset")) {
+      if (h->exp_words) hipFree(h->exp_words);
+      h->exp_words = nullptr;
+      return false;
+    }
+    h->exp_words_bytes = cap;
+    h->exp_epoch = 0;
+  }
+  if (const char *e = getenv("OZIMMU_HIP_TEST_EXP_EPOCH")) // test hook: jump close to the wrap-around
+    if (h->exp_epoch < (uint32_t)std::atoi(e)) h->exp_epoch = (uint32_t)std::atoi(e);
+  if (++h->exp_epoch >= (1u << 21)) { // the tag field is 21 bits: start over on zeroed words (stream ordered)
+    if (!hip_ok(hipMemsetAsync(h->exp_words, 0, h->exp_words_bytes, h->stream), "memset")) return false;
+    h->exp_epoch = 1;
+  }
+  x.tag = h->exp_epoch << 11;
+  char *base = reinterpret_cast<char *>(h->exp_words);
+  for (int i = 0; i < parts; i++) {
+    x.a[i] = reinterpret_cast<uint32_t *>(base + (size_t)i * ea);
+    x.b[i] = reinterpret_cast<uint32_t *>(base + (size_t)parts * ea + (size_t)i * eb);
+  }
+  return true;
+}
+
+// the phase hints / claim counters of a call: eight 256-byte lines that the slice GEMM expects zeroed
+static bool zero_phase_lines(ozimmu_hip_handle_t h, uint32_t *phase) {
+  return hip_ok(launch_zero_words(phase, 8 * 256, 0, 1, h->stream), "zero_words");
+}
+
+// The per-XCD phase hints and the tile queues of the persistent wide kernel only pay for problems with more tiles than
+// CUs; below that the launch is one tile per workgroup (K-split kernel, or a single round of the classic / wide kernel)
+// and the call saves the zeroing launch: three launches per small DGEMM (row maxima, cut, GEMM).
+static bool wants_phase(size_t m, size_t n, size_t batch) {
+  return batch == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) && m * n >= (size_t)2560 * 1024;
 }
 
 // Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
@@ -245,7 +291,7 @@ struct WorkspaceUse {
   }
 };
 
-static bool stream_is_capturing(hipStream_t stream) {
+bool stream_is_capturing(hipStream_t stream) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
     (void)hipGetLastError();
@@ -286,31 +332,33 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   ba.in_stride = bs.stride_a;
   bb.in_stride = bs.stride_b;
   ba.ws_stride = bb.ws_stride = slot;
+  ExpWords xw;
+  if (!exp_words(h, m, n, 1, bs.count, xw)) return 3;
+  ba.exps_stride = bb.exps_stride = xw.pitch;
+  ba.tag = bb.tag = xw.tag;
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  const bool use_phase = bs.count == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false);
+  const bool use_phase = wants_phase(m, n, bs.count);
+  if (use_phase && !zero_phase_lines(h, w.phase)) return 3;
   if (one_pass_split(8 * (m + n) * k * bs.count)) {
-    // both operands (and every matrix of the batch) in one launch; only the phase hint words need zeroing
-    if (use_phase && !hip_ok(launch_zero_words(w.phase, 8 * 256, 0, 1, h->stream), "zero_words")) return 3;
+    // both operands (and every matrix of the batch) in one launch
     const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, nullptr},
                               {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, nullptr}};
     if (!hip_ok(launch_split_fused(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot), "split")) return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3; // split_A + split_B -> split_A
   } else if (multi_view_split(8 * (m + n) * k * bs.count)) {
-    // A and B in one launch per pass: memset, row maxima, cut, GEMM = 4 launches (in the stage report the row-max
-    // pass is booked under split_A and the cut pass under split_B)
-    if (!zero_slot_heads(h, w.exps_a, w.exps_bytes, slot, bs.count)) return 3;
-    const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, w.exps_a},
-                              {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, w.exps_b}};
-    if (!hip_ok(launch_row_max_multi(jobs, 2, h->stream, (uint32_t)bs.count, slot), "row_max_exp")) return 3;
+    // A and B in one launch per pass: row maxima, cut, GEMM = 3 launches (in the stage report the row-max pass is
+    // booked under split_A and the cut pass under split_B)
+    const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, xw.a[0]},
+                              {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, xw.b[0]}};
+    if (!hip_ok(launch_row_max_multi(jobs, 2, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "row_max_exp")) return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
-    if (!hip_ok(launch_cut_multi(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot), "cut")) return 3;
+    if (!hip_ok(launch_cut_multi(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "cut")) return 3;
   } else {
-    if (!zero_slot_heads(h, w.exps_a, w.exps_bytes, slot, bs.count)) return 3;
-    if (!run_split(h, view_A(op_A, m, k, a, lda), w.exps_a, S, L, w.planes_a, w.ea, ba)) return 3;
+    if (!run_split(h, view_A(op_A, m, k, a, lda), xw.a[0], S, L, w.planes_a, w.ea, ba)) return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
-    if (!run_split(h, view_B(op_B, k, n, b, ldb), w.exps_b, S, L, w.planes_b, w.eb, bb)) return 3;
+    if (!run_split(h, view_B(op_B, k, n, b, ldb), xw.b[0], S, L, w.planes_b, w.eb, bb)) return 3;
   }
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
 
@@ -373,11 +421,11 @@ static OperandView view_B_part(ozimmu_operation_t op, size_t k, size_t n, const 
 }
 
 struct WorkspaceZ {
-  uint32_t *exps_a[2], *exps_b[2], *phase;
+  uint32_t *phase;
   double *ea[2], *eb[2];
   int8_t *planes_a[2], *planes_b[2];
   double *acc;
-  size_t exps_bytes, total;
+  size_t total;
 };
 
 static WorkspaceZ carve_z(void *base, size_t m, size_t n, size_t k, int S, bool need_acc) {
@@ -388,10 +436,7 @@ static WorkspaceZ carve_z(void *base, size_t m, size_t n, size_t k, int S, bool 
     off += align256(bytes);
     return p;
   };
-  for (int i = 0; i < 2; i++) w.exps_a[i] = (uint32_t *)take(4 * m);
-  for (int i = 0; i < 2; i++) w.exps_b[i] = (uint32_t *)take(4 * n);
   w.phase = (uint32_t *)take(8 * 256);
-  w.exps_bytes = off;
   for (int i = 0; i < 2; i++) w.ea[i] = (double *)take(8 * m);
   for (int i = 0; i < 2; i++) w.eb[i] = (double *)take(8 * n);
   for (int i = 0; i < 2; i++) w.planes_a[i] = (int8_t *)take(tiled_plane_bytes(m, k, S));
@@ -423,12 +468,16 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   ba.in_stride = 2 * bs.stride_a;
   bb.in_stride = 2 * bs.stride_b;
   ba.ws_stride = bb.ws_stride = slot;
+  ExpWords xw;
+  if (!exp_words(h, m, n, 2, bs.count, xw)) return 3;
+  ba.exps_stride = bb.exps_stride = xw.pitch;
+  ba.tag = bb.tag = xw.tag;
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  const bool use_phase = bs.count == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false);
+  const bool use_phase = wants_phase(m, n, bs.count);
+  if (use_phase && !zero_phase_lines(h, w.phase)) return 3;
   if (one_pass_split(16 * (m + n) * k * bs.count)) {
-    if (use_phase && !hip_ok(launch_zero_words(w.phase, 8 * 256, 0, 1, h->stream), "zero_words")) return 3;
     const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, nullptr},
                               {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, nullptr},
                               {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, nullptr},
@@ -436,22 +485,20 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     if (!hip_ok(launch_split_fused(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot), "split")) return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
   } else if (multi_view_split(16 * (m + n) * k * bs.count)) {
-    if (!zero_slot_heads(h, w.exps_a[0], w.exps_bytes, slot, bs.count)) return 3;
-    const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, w.exps_a[0]},
-                              {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, w.exps_a[1]},
-                              {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, w.exps_b[0]},
-                              {view_B_part(op_B, k, n, b, ldb, 1), w.planes_b[1], w.eb[1], bb.in_stride, w.exps_b[1]}};
-    if (!hip_ok(launch_row_max_multi(jobs, 4, h->stream, (uint32_t)bs.count, slot), "row_max_exp")) return 3;
+    const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, xw.a[0]},
+                              {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, xw.a[1]},
+                              {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, xw.b[0]},
+                              {view_B_part(op_B, k, n, b, ldb, 1), w.planes_b[1], w.eb[1], bb.in_stride, xw.b[1]}};
+    if (!hip_ok(launch_row_max_multi(jobs, 4, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "row_max_exp")) return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
-    if (!hip_ok(launch_cut_multi(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot), "cut")) return 3;
+    if (!hip_ok(launch_cut_multi(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "cut")) return 3;
   } else {
-    if (!zero_slot_heads(h, w.exps_a[0], w.exps_bytes, slot, bs.count)) return 3;
     for (int part = 0; part < 2; part++)
-      if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), w.exps_a[part], S, L, w.planes_a[part], w.ea[part], ba))
+      if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), xw.a[part], S, L, w.planes_a[part], w.ea[part], ba))
         return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
     for (int part = 0; part < 2; part++)
-      if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), w.exps_b[part], S, L, w.planes_b[part], w.eb[part], bb))
+      if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), xw.b[part], S, L, w.planes_b[part], w.eb[part], bb))
         return 3;
   }
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
@@ -616,6 +663,7 @@ int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
     }
     if (h->working_memory_ptr) hipFree(h->working_memory_ptr);
     if (h->d_mantissa_loss_counter_ptr) hipFree(h->d_mantissa_loss_counter_ptr);
+    if (h->exp_words) hipFree(h->exp_words);
     for (auto &e : h->ev)
       if (e) hipEventDestroy(e);
     if (h->tail_ev) hipEventDestroy(h->tail_ev);

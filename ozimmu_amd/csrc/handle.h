@@ -22,6 +22,12 @@ struct ozimmu_hip_handle {
 
   // auto mode: 16 counters for S = 3..18 (the reference allocates 8: src/handle.hpp:22)
   unsigned long long *d_mantissa_loss_counter_ptr = nullptr;
+
+  // row exponent words of the split (kernels.h: SplitJobs::tag): a buffer that holds nothing else, written with a tag
+  // that grows from call to call, so that it is zeroed once when it is allocated and never per call
+  uint32_t *exp_words = nullptr;
+  size_t exp_words_bytes = 0;
+  uint32_t exp_epoch = 0;
   double avg_mantissa_loss_threshold = 0; // src/handle.hpp:26
 
   // src/handle.hpp:28-30, read at creation (src/handle.cu:25-30)

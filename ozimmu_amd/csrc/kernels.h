@@ -50,6 +50,8 @@ struct Batch {
   uint32_t count = 1;
   long long in_stride = 0;
   size_t ws_stride = 0;
+  size_t exps_stride = 0; // bytes between the exponent words of consecutive matrices
+  uint32_t tag = 0;       // see SplitJobs::tag
 };
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream);
@@ -74,7 +76,7 @@ struct OperandView {
   size_t stride_r, stride_k;
 };
 
-// exps[r] = max over k of the biased exponent field (11 bits) of row r; exps must be zeroed first
+// exps[r] = batch.tag | max over k of the biased exponent field (11 bits) of row r (SplitJobs::tag; tag 0: exps zeroed first)
 hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream, const Batch &batch = Batch());
 
 // slices -> tiled planes (layout.h) and max_exp[r] = 2^(e_max+1) (0 for zero rows, NaN for poisoned rows)
@@ -97,14 +99,20 @@ struct SplitJobs {
   uint32_t kchunk[4]; // row_max: k values per workgroup
   int count, S, L;
   size_t ws_stride;
+  size_t exps_stride; // bytes between the exponent words of consecutive matrices of a batch
+  // Exponent words are written with atomicMax(tag | e), e = 11-bit exponent field, tag = call epoch << 11, and a reader
+  // takes a word whose upper bits differ from the tag as "no element seen" (0).  With an epoch that grows from call to
+  // call in a buffer that holds nothing but such words, the words never need zeroing; tag = 0 is the plain form for
+  // freshly zeroed memory.
+  uint32_t tag;
 };
 // the two streaming passes for up to 4 views x `batch` matrices in one launch each (small problems: launch bound)
 // zero `bytes` at the head of `count` workspace slots `pitch` bytes apart (exponent words, phase hints, claim counters)
 hipError_t launch_zero_words(void *base, size_t bytes, size_t pitch, uint32_t count, hipStream_t stream);
 hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stream, uint32_t batch = 1,
-                                size_t ws_stride = 0);
+                                size_t ws_stride = 0, size_t exps_stride = 0, uint32_t tag = 0);
 hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch = 1,
-                            size_t ws_stride = 0);
+                            size_t ws_stride = 0, size_t exps_stride = 0, uint32_t tag = 0);
 hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch = 1,
                               size_t ws_stride = 0);
 

@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // ---- pass 1: per-row maximum exponent field ---------------------------------------------------------
 // k-contiguous operand: element (r,k) at in[r*ld + k].  One wave per row segment, lanes along k.
 __device__ __forceinline__ void row_max_kcontig(const double *__restrict__ in, size_t rows, size_t K, size_t sr,
-                                                size_t sk, uint32_t *exps, unsigned kchunk, size_t bx, size_t by) {
+                                                size_t sk, uint32_t *exps, unsigned kchunk, size_t bx, size_t by,
+                                                uint32_t tag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t r = bx * 4 + wave;
   if (r >= rows) return;
@@ -71,13 +72,13 @@ __device__ __forceinline__ void row_max_kcontig(const double *__restrict__ in, s
     e = t > e ? t : e;
   }
   e = wave_max_u32(e);
-  if (lane == 0 && e) atomicMax(exps + r, e);
+  if (lane == 0 && e) atomicMax(exps + r, tag | e);
 }
 
 // row-contiguous operand: element (r,k) at in[k*ld + r].  Lanes along r, the 4 waves interleave k.
 __device__ __forceinline__ void row_max_rcontig(const double *__restrict__ in, size_t rows, size_t K, size_t sr,
                                                 size_t sk, uint32_t *exps, unsigned kchunk, size_t bx, size_t by,
-                                                unsigned (*red)[64]) {
+                                                unsigned (*red)[64], uint32_t tag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t r = bx * 64 + lane;
   const size_t k0 = by * kchunk;
@@ -104,7 +105,7 @@ __device__ __forceinline__ void row_max_rcontig(const double *__restrict__ in, s
     e = red[0][lane];
 #pragma unroll
     for (int w = 1; w < 4; w++) e = red[w][lane] > e ? red[w][lane] : e;
-    if (r < rows && e) atomicMax(exps + r, e);
+    if (r < rows && e) atomicMax(exps + r, tag | e);
   }
 }
 
@@ -127,19 +128,22 @@ __global__ __launch_bounds__(256) void row_max_kernel(const SplitJobs jobs) {
   if (ji == 2) j = jobs.job[2], nx = jobs.nx[2], kchunk = jobs.kchunk[2];
   if (ji == 3) j = jobs.job[3], nx = jobs.nx[3], kchunk = jobs.kchunk[3];
   const double *in = j.v.in + (long long)blockIdx.z * j.in_stride;
-  uint32_t *exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(j.exps) + (size_t)blockIdx.z * jobs.ws_stride);
+  uint32_t *exps = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(j.exps) + (size_t)blockIdx.z * jobs.exps_stride);
   const uint32_t bx = blk % nx, by = blk / nx;
   if (j.v.stride_k < j.v.stride_r)
-    row_max_kcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, kchunk, bx, by);
+    row_max_kcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, kchunk, bx, by, jobs.tag);
   else
-    row_max_rcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, kchunk, bx, by, red);
+    row_max_rcontig(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, kchunk, bx, by, red, jobs.tag);
 }
 
-hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stream, uint32_t batch, size_t ws_stride) {
+hipError_t launch_row_max_multi(const SplitJob *job, int count, hipStream_t stream, uint32_t batch, size_t ws_stride,
+                                size_t exps_stride, uint32_t tag) {
   if (count < 1 || count > 4) return hipErrorInvalidValue;
   SplitJobs jobs{};
   jobs.count = count;
   jobs.ws_stride = ws_stride;
+  jobs.exps_stride = exps_stride;
+  jobs.tag = tag;
   uint64_t total = 0;
   for (int i = 0; i < count; i++) {
     const OperandView &v = job[i].v;
@@ -183,7 +187,7 @@ hipError_t launch_zero_words(void *base, size_t bytes, size_t pitch, uint32_t co
 
 hipError_t launch_row_max_exp(const OperandView &v, uint32_t *exps, hipStream_t stream, const Batch &b) {
   const SplitJob job{v, nullptr, nullptr, b.in_stride, exps};
-  return launch_row_max_multi(&job, 1, stream, b.count, b.ws_stride);
+  return launch_row_max_multi(&job, 1, stream, b.count, b.ws_stride, b.exps_stride, b.tag);
 }
 
 // ---- shared: load one 32 rows x 32 k block, lane (r = lane&31, kh = lane>>5) gets its 16 k values ---
@@ -241,6 +245,9 @@ __device__ __forceinline__ void load_block(const double *__restrict__ in, size_t
 // ---- the cut itself: 16 k values of one row -> S x 16 slice bytes (src/split.cu:154-185) ------------------------------
 // e = the row's maximum exponent field.  e == 0: zero/subnormal row -> max_exp 0, zero slices (reference: 0*2 = 0,
 // src/split.cu:191); e >= 0x7FE: Inf/NaN in the row, or 2^(e+1) not representable -> poisoned row (max_exp = NaN).
+// exponent field of a tagged exponent word (SplitJobs::tag); a word left by an earlier epoch reads as "nothing seen"
+__device__ __forceinline__ unsigned tagged_exp(uint32_t w, uint32_t tag) { return (w & ~0x7FFu) == tag ? (w & 0x7FFu) : 0u; }
+
 __device__ __forceinline__ double max_exp_of(unsigned e) {
   const bool live = e != 0u && e < 0x7FEu;
   const unsigned long long bits = live ? ((unsigned long long)(e + 1) << 52) : (e == 0u ? 0ull : 0x7FF8000000000000ull);
@@ -336,7 +343,7 @@ template <bool KCONTIG, bool PREFETCH = KCONTIG, bool LOW = true>
 __device__ __forceinline__ void cut_body(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
                                          const uint32_t *__restrict__ exps, int S, int L, int8_t *__restrict__ planes,
                                          double *__restrict__ max_exp, size_t RB, size_t KB, int strip, size_t block,
-                                         double (*tiles)[32][33]) {
+                                         double (*tiles)[32][33], uint32_t tag) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int CUT_STRIP = PREFETCH ? strip : 1;
   // strips along the contiguous axis: k-contiguous -> CUT_STRIP k-blocks of one row-block, else CUT_STRIP row-blocks
@@ -374,7 +381,7 @@ __device__ __forceinline__ void cut_body(const double *__restrict__ in, size_t r
 
     const int r = lane & 31;
     const size_t rg = rb * 32 + r;
-    const unsigned e = rg < rows ? exps[rg] : 0u;
+    const unsigned e = rg < rows ? tagged_exp(exps[rg], tag) : 0u;
     if (kb == 0 && lane < 32 && rg < rows) max_exp[rg] = max_exp_of(e);
     cut_and_store<LOW>(v, e, S, L, planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)lane * 16);
   }
@@ -387,13 +394,13 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
                                                   size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
                                                   int8_t *__restrict__ planes, double *__restrict__ max_exp,
                                                   size_t RB, size_t KB, int strip, long long in_stride,
-                                                  size_t ws_stride) {
+                                                  size_t ws_stride, size_t exps_stride, uint32_t tag) {
   __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
   in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
-  exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(exps) + (size_t)blockIdx.z * ws_stride);
+  exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(exps) + (size_t)blockIdx.z * exps_stride);
   planes += (size_t)blockIdx.z * ws_stride;
   max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(max_exp) + (size_t)blockIdx.z * ws_stride);
-  cut_body<KCONTIG, PREFETCH, LOW>(in, rows, K, sr, sk, exps, S, L, planes, max_exp, RB, KB, strip, blockIdx.x, tiles);
+  cut_body<KCONTIG, PREFETCH, LOW>(in, rows, K, sr, sk, exps, S, L, planes, max_exp, RB, KB, strip, blockIdx.x, tiles, tag);
 }
 
 // up to 4 operand views per launch (see row_max_kernel): the form for small problems
@@ -417,15 +424,15 @@ __global__ __launch_bounds__(256) void cut_multi_kernel(const SplitJobs jobs) {
   if (ji == 3) j = jobs.job[3], strip = jobs.nx[3];
   const size_t off = (size_t)blockIdx.z * jobs.ws_stride;
   const double *in = j.v.in + (long long)blockIdx.z * j.in_stride;
-  const uint32_t *exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(j.exps) + off);
+  const uint32_t *exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(j.exps) + (size_t)blockIdx.z * jobs.exps_stride);
   double *max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + off);
   const size_t RB = (j.v.rows + TILE_ROWS - 1) / TILE_ROWS * (TILE_ROWS / FRAG_ROWS), KB = (j.v.K + FRAG_K - 1) / FRAG_K;
   if (j.v.stride_k < j.v.stride_r)
     cut_body<true, PF, LOW>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp, RB,
-                       KB, (int)strip, blk, tiles);
+                       KB, (int)strip, blk, tiles, jobs.tag);
   else
     cut_body<false, false, LOW>(in, j.v.rows, j.v.K, j.v.stride_r, j.v.stride_k, exps, jobs.S, jobs.L, j.planes + off, max_exp,
-                           RB, KB, 1, blk, tiles);
+                           RB, KB, 1, blk, tiles, jobs.tag);
 }
 
 static int cut_strip_for(bool kcontig, size_t RB, size_t KB) {
@@ -439,13 +446,15 @@ static int cut_strip_for(bool kcontig, size_t RB, size_t KB) {
 }
 
 hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch,
-                            size_t ws_stride) {
+                            size_t ws_stride, size_t exps_stride, uint32_t tag) {
   if (count < 1 || count > 4) return hipErrorInvalidValue;
   SplitJobs jobs{};
   jobs.count = count;
   jobs.S = S;
   jobs.L = L;
   jobs.ws_stride = ws_stride;
+  jobs.exps_stride = exps_stride;
+  jobs.tag = tag;
   uint64_t total = 0;
   for (int i = 0; i < count; i++) {
     const OperandView &v = job[i].v;
@@ -482,19 +491,19 @@ hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, 
   const bool low = S * L > 64; // some slice reaches into the lower 64 bits of the shifted mantissa
   if (kcontig && strip == 1 && low) // no strip to prefetch along: the register-lean form (4 waves per SIMD instead of 2)
     hipLaunchKernelGGL((cut_kernel<true, false, true>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
   else if (kcontig && strip == 1)
     hipLaunchKernelGGL((cut_kernel<true, false, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
   else if (kcontig)
     hipLaunchKernelGGL(cut_kernel<true>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
   else if (low)
     hipLaunchKernelGGL((cut_kernel<false, false, true>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
   else
     hipLaunchKernelGGL((cut_kernel<false, false, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
   return hipGetLastError();
 }
 

@@ -417,3 +417,32 @@ def test_call_after_the_previous_calls_stream_was_destroyed(oz):
     assert st == 0
     for c in (c1, c2):
         np.testing.assert_array_equal(c.cpu().numpy().view(np.uint64), c_ref.buf.view(np.uint64))
+
+
+def test_exponent_word_epoch_wraps_around(monkeypatch):
+    """the split's row-exponent words are never zeroed per call: they carry the epoch of the call that wrote them and a
+    reader ignores words of other epochs.  The epoch has 21 bits; OZIMMU_HIP_TEST_EXP_EPOCH jumps a fresh handle to just
+    below the wrap-around, and calls of alternating shapes (stale words of the larger problem under the smaller one, zero
+    rows that write nothing) must stay bit-exact across it"""
+    import torch
+    monkeypatch.setenv("OZIMMU_HIP_TEST_EXP_EPOCH", str((1 << 21) - 4))
+    h = ozimmu_amd.create()
+    try:
+        rng = np.random.default_rng(99)
+        for it, (m, n, k) in enumerate([(300, 200, 64), (90, 70, 33), (300, 200, 64), (64, 260, 100), (90, 70, 33),
+                                        (300, 200, 64), (33, 35, 37), (300, 200, 64)]):
+            if it == 2:
+                monkeypatch.delenv("OZIMMU_HIP_TEST_EXP_EPOCH")  # from here on the epoch runs freely through the wrap
+            a = operand("N", m, k, rng)
+            b = operand("T", k, n, rng)
+            a.buf[:, 3] = 0.0  # row 3 of op(A) is zero: nothing is written to its exponent word
+            a._dev = None
+            c = ColMajor(m, n)
+            c_ref = ColMajor(m, n)
+            assert ozimmu_amd.gemm(h, "N", "T", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, "fp64_int8_8") == 0
+            torch.cuda.synchronize()
+            assert O.gemm("N", "T", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, 8, O.ORDER_DIAGONAL) == 0
+            np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64), err_msg=f"call {it}")
+    finally:
+        torch.cuda.synchronize()
+        ozimmu_amd.destroy(h)
