@@ -236,9 +236,9 @@ static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipSt
 // chip, else the classic one
 template <int S, int D0, int ND, int FORCE_WM = 0>
 static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
-  // S <= 4: few MFMAs per staged byte even on 128x128 tiles; the classic 8-wave 128x64 kernel measures faster
-  // (4096^3: S=3 241 vs 214, S=4 174 vs 168 TFLOP/s; from S=5 on the wide kernel leads by 6-13 %)
-  constexpr bool wide_pays = ND >= 5 || D0 > 0;
+  // S = 3: few MFMAs per staged byte even on 128x128 tiles; the classic 8-wave 128x64 kernel measures faster (4096^3,
+  // profiles/r2_sweeps: 263 vs 245 TFLOP/s); from S = 4 on the wide kernel leads (193 vs 179, then by 8-20 %)
+  constexpr bool wide_pays = ND >= 4 || D0 > 0;
   if constexpr (K2Cfg<S, D0, ND>::ok) {
     // no more 64x64 tiles than CUs (all matrices of a batch together): the classic kernel would run one wave per SIMD;
     // split K inside an 8-wave workgroup instead (slice_gemm_k2_kernel.h; 1024^3 S=9: 48.6 -> see DESIGN.md)

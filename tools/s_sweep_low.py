@@ -1,0 +1,20 @@
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+for n in (1536, 2048, 3072, 4096, 8192):
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    for S in (3, 4):
+        out = []
+        for kern in (None, "classic", "wide"):
+            if kern: os.environ["OZIMMU_HIP_GEMM_KERNEL"] = kern
+            else: os.environ.pop("OZIMMU_HIP_GEMM_KERNEL", None)
+            def call(): assert oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, f"fp64_int8_{S}") == 0
+            reps = max(4, int(2e11 / n**3))
+            call(); call(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps): call()
+            torch.cuda.synchronize(); t = (time.perf_counter() - t0) / reps
+            out.append(f"{kern or 'default'} {2*n**3/t/1e12:6.1f}")
+        print(f"n={n} S={S}: " + "  ".join(out), flush=True)
