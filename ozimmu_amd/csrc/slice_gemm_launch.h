@@ -192,13 +192,15 @@ static WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) {
 // bench_kernel_choice.py: 1536^3 = 192 tiles: 177 vs 211 us; 2048^3 339 vs 347; 3072^3 1006 vs 1124; 8192^3 16.9 vs
 // 19.5 ms; at 1024^3 its 128 tiles of 64x128 lose to the classic kernel's 256 of 64x64: 92 vs 76 us).
 // OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements, parity tests of both kernels on small shapes).
-static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu) {
+// With 8 or more diagonals the classic kernel's 64x64 tiles stage so much per MFMA that the wide kernel already wins
+// on ~40 % of the CUs (tools/sweep_policy.py, 1152^3: S = 9 77 vs 85 us, but S = 6 64 vs 53 us).
+static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu, int diagonals) {
   if (const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL")) {
     if (!std::strcmp(e, "wide")) return true;
     if (!std::strcmp(e, "classic")) return false;
   }
   const uint64_t wgs = (uint64_t)(pl.n_big + pl.n_small) * tn;
-  return 10 * wgs >= 7 * (uint64_t)ncu;
+  return 10 * wgs >= (diagonals >= 8 ? 4u : 7u) * (uint64_t)ncu;
 }
 
 template <int S, int D0, int ND>
@@ -254,7 +256,7 @@ static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
     const int ncu_eff = (int)(ncu / nbatch) > 0 ? (int)(ncu / nbatch) : 1;
     const WidePlan pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu_eff);
     if constexpr (WideCfg<S, D0, ND>::ok)
-      if (prefer_wide(pl, (a.N + 127) / 128, ncu_eff)) return launch_wide<S, D0, ND>(a, pl, stream);
+      if (prefer_wide(pl, (a.N + 127) / 128, ncu_eff, ND)) return launch_wide<S, D0, ND>(a, pl, stream);
   }
   return launch_one<S, D0, ND, FORCE_WM>(a, stream);
 }

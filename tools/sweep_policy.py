@@ -1,0 +1,25 @@
+"""Does the kernel-choice policy pick the fastest kernel?  fp64_int8_9 (or argv[1]) at small / mid square sizes: default
+vs each forced kernel (whole-call time)."""
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+for n in (640, 768, 896, 1024, 1152, 1280, 1408, 1536, 1664, 1792, 1920, 2048, 2304):
+    a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    def call(): assert oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, f"fp64_int8_{S}") == 0
+    res = {}
+    for r in range(3):
+        for kern in (None, "k2", "classic", "wide"):
+            if kern: os.environ["OZIMMU_HIP_GEMM_KERNEL"] = kern
+            else: os.environ.pop("OZIMMU_HIP_GEMM_KERNEL", None)
+            for _ in range(5): call()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(100): call()
+            torch.cuda.synchronize(); res.setdefault(kern, []).append((time.perf_counter() - t0) / 100 * 1e6)
+    t = {k: sorted(v)[1] for k, v in res.items()}
+    best = min((v, k) for k, v in t.items() if k)[1]
+    print(f"n={n}: default {t[None]:7.1f} us | k2 {t['k2']:7.1f} | classic {t['classic']:7.1f} | wide {t['wide']:7.1f} | best {best}"
+          f"{'' if t[None] <= 1.02 * t[best] else '   <-- policy loses %.0f %%' % ((t[None] / t[best] - 1) * 100)}", flush=True)
