@@ -192,15 +192,15 @@ static WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) {
 // bench_kernel_choice.py: 1536^3 = 192 tiles: 177 vs 211 us; 2048^3 339 vs 347; 3072^3 1006 vs 1124; 8192^3 16.9 vs
 // 19.5 ms; at 1024^3 its 128 tiles of 64x128 lose to the classic kernel's 256 of 64x64: 92 vs 76 us).
 // OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements, parity tests of both kernels on small shapes).
-// With 8 or more diagonals the classic kernel's 64x64 tiles stage so much per MFMA that the wide kernel already wins
+// With 8 or more staged slices the classic kernel's 64x64 tiles stage so much per MFMA that the wide kernel already wins
 // on ~40 % of the CUs (tools/sweep_policy.py, 1152^3: S = 9 77 vs 85 us, but S = 6 64 vs 53 us).
-static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu, int diagonals) {
+static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu, int staged_slices) {
   if (const char *e = getenv("OZIMMU_HIP_GEMM_KERNEL")) {
     if (!std::strcmp(e, "wide")) return true;
     if (!std::strcmp(e, "classic")) return false;
   }
   const uint64_t wgs = (uint64_t)(pl.n_big + pl.n_small) * tn;
-  return 10 * wgs >= (diagonals >= 8 ? 4u : 7u) * (uint64_t)ncu;
+  return 10 * wgs >= (staged_slices >= 8 ? 4u : 7u) * (uint64_t)ncu;
 }
 
 template <int S, int D0, int ND>
@@ -255,8 +255,32 @@ static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
     const uint32_t nbatch = a.batch > 1 ? a.batch : 1;
     const int ncu_eff = (int)(ncu / nbatch) > 0 ? (int)(ncu / nbatch) : 1;
     const WidePlan pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu_eff);
+    // Two cases where the classic kernel's small tiles win although the wide tiles would fill the chip (tools/
+    // sweep_policy_random.py: losses of 15-50 % without these rules):
+    //  * a short k loop: a wide tile pays ~8 us of claim / prologue / epilogue per tile whatever K is, against a k loop of
+    //    nk x (WA x pairs) MFMAs x 19.4 ns (32 cycles at ~1.65 GHz); below ~40 us of loop the two-workgroups-per-CU
+    //    kernel hides its tile boundaries better (K <= 512 at S = 8..9, K <= 1024 at S = 4); with 10 / 11+ staged
+    //    slices the classic kernel is down to one workgroup per CU and the bar drops to 30 / 15 us (K = 128 only);
+    //  * few diagonals and a tile count that quantises badly (e.g. 300 tiles of 128x128 on 256 CUs): with S < 8 the
+    //    wide kernel's margin per block is too small to pay for a half-empty last round.
+    constexpr int PAIRS = []() {
+      int c = 0;
+      for (int i = 0; i < S; i++)
+        for (int j = 0; j < S; j++) c += (i + j >= D0 && i + j < D0 + ND && i + j <= S - 1) ? 1 : 0;
+      return c;
+    }();
+    const double loop_us = (double)(a.kb1 - a.kb0) * (WideCfg<S, D0, ND>::WA * PAIRS) * 0.0194;
+    // With up to 5 slices the wide kernel leads by 6-8 % only when its tiles fill the chip evenly (4096^3: 184 vs 169
+    // TFLOP/s at S = 4; 3163 x 1515 x 8192: 621 vs 575 us the other way).  The second pass of S >= 13 stages 11+ slices:
+    // there the classic kernel is down to one 8-wave workgroup per CU and loses at any size and K.
+    constexpr int SL = WideCfg<S, D0, ND>::SL;
+    constexpr bool second_pass = D0 > 0 && SL >= 11;
+    const bool classic_wins = !getenv("OZIMMU_HIP_GEMM_KERNEL") && !second_pass &&
+                              (loop_us < (SL >= 11 ? 15.0 : SL == 10 ? 30.0 : 40.0) ||
+                               (SL < 8 && pl.efficiency < (SL <= 5 ? 0.9 : 0.62)));
     if constexpr (WideCfg<S, D0, ND>::ok)
-      if (prefer_wide(pl, (a.N + 127) / 128, ncu_eff, ND)) return launch_wide<S, D0, ND>(a, pl, stream);
+      if (!classic_wins && (second_pass || prefer_wide(pl, (a.N + 127) / 128, ncu_eff, SL)))
+        return launch_wide<S, D0, ND>(a, pl, stream);
   }
   return launch_one<S, D0, ND, FORCE_WM>(a, stream);
 }
