@@ -6,9 +6,9 @@ for n in (1536, 2048, 3072, 4096, 8192):
     a = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
     b = torch.rand(n, n, dtype=torch.float64, device="cuda") * 2 - 1
     c = torch.zeros(n, n, dtype=torch.float64, device="cuda")
-    for S in (3, 4):
+    for S in (3, 4, 5):
         out = []
-        for kern in (None, "classic", "wide"):
+        for kern in (None, "classic", "wide", "k2"):
             if kern: os.environ["OZIMMU_HIP_GEMM_KERNEL"] = kern
             else: os.environ.pop("OZIMMU_HIP_GEMM_KERNEL", None)
             def call(): assert oz.gemm(h, "N", "N", n, n, n, 1.0, a, n, b, n, 0.0, c, n, f"fp64_int8_{S}") == 0
