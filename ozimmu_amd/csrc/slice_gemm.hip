@@ -4,11 +4,15 @@
 //   for each pair (i,j), i+j <= S+1:  cublasGemmEx(INT8->INT32)  (/root/reference/src/gemm.cu:315-329)
 //                                     accumulate_in_f64            (src/gemm.cu:77-102, :394-401)
 //   axby                                                           (src/gemm.cu:124-158)
-// by ONE kernel per pass (slice_gemm_kernel.h) that keeps a 64x64 output tile resident in registers:
+// by ONE kernel per pass that keeps its output tile resident in registers -- three kernels share the arithmetic below
+// and the epilogue: slice_gemm_w_kernel.h (one workgroup per CU, (32*WA) x 128 tiles, persistent: the kernel of every
+// problem that fills the chip), slice_gemm_k2_kernel.h (64x64 tiles, K split inside an 8-wave workgroup: launches with
+// at most one tile per CU) and slice_gemm_kernel.h (64x64 / 128x64 tiles, two workgroups per CU: short k loops, few
+// slices); slice_gemm_launch.h chooses.  In all of them:
 //
-//  * every k-step (32 k-bytes) the workgroup stages ALL needed slices of its 64 A-rows and 64 B-rows
+//  * every k-step (32 k-bytes) the workgroup stages ALL needed slices of its A-rows and B-rows
 //    HBM -> LDS with global_load_lds (1 KiB fragment blocks, layout.h), double buffered;
-//  * each of the 4 waves owns a 32x32 sub-tile and issues one v_mfma_i32_32x32x32_i8 per slice pair,
+//  * a wave owns 32x32 sub-tiles and issues one v_mfma_i32_32x32x32_i8 per slice pair and sub-tile,
 //    accumulating pairs of equal i+j (same power-of-two weight) into the SAME INT32 accumulator:
 //    S accumulators instead of S(S+1)/2 products.  Integer addition is exact, so this only regroups
 //    the reference's sum; the INT32 bound count*K*(2^L-1)^2 < 2^31 is enforced by the host through
