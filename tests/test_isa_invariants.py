@@ -28,12 +28,13 @@ def asm(tmp_path_factory):
     sys.path.insert(0, ROOT)
     from ozimmu_amd import build as B
     d = tmp_path_factory.mktemp("isa")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]  # what a .hip can include
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
 
     def device_asm(src):
         # the library build (python -m ozimmu_amd.build, -save-temps=obj) leaves the device assembly behind: use it if
         # it is newer than every source, else compile
         kept = B.device_asm_path(src)
+        deps = headers + [os.path.join(CSRC, src)]
         if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(f) for f in deps):
             return open(kept).read()
         o = d / (src + ".s")
