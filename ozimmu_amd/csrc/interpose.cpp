@@ -66,10 +66,18 @@ template <class F> F original(const char *name) { return reinterpret_cast<F>(ven
 ozimmu_compute_mode_t get_compute_mode() { return ozimmu_hip_compute_mode_from_str(getenv("OZIMMU_COMPUTE_MODE")); }
 
 // src/cublas.cu:60-86
-ozimmu_hip_handle_t get_global_handle() {
+// `stream`: the caller's stream.  The handle of a device is created on its first intercepted call (device allocations);
+// if that call happens while its stream is being captured into a graph, nothing may be allocated: the call is left to the
+// vendor routine and the handle is created by a later, uncaptured call.
+ozimmu_hip_handle_t get_global_handle(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_mtx);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0; // no device: ozimmu_hip_create below fails and is reported
+  if (g_handles.find(dev) == g_handles.end() || !g_handles[dev]) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;
+    (void)hipGetLastError();
+  }
   ozimmu_hip_handle_t &g_handle = g_handles[dev];
   if (!g_handle) {
     const ozimmu_malloc_mode_t mm = env_enabled("OZIMMU_MALLOC_ASYNC", false) ? OZIMMU_MALLOC_ASYNC : OZIMMU_MALLOC_SYNC;
@@ -128,7 +136,7 @@ Try try_ozaki(hipStream_t stream, bool host_pointer_mode, const GemmCall &g) {
   if (!host_pointer_mode || g.m < 0 || g.n < 0 || g.k < 0 || g.batch < 1 || !g.alpha || !g.beta) return Try::NotTaken;
   // the kernels index rows / columns with 32 bits and the slice width is defined up to k = 2^30 (src/split.cu:520-536)
   if (g.m >= (1ll << 31) || g.n >= (1ll << 31) || g.k > (1ll << 30) || g.batch >= (1ll << 31)) return Try::NotTaken;
-  ozimmu_hip_handle_t h = get_global_handle();
+  ozimmu_hip_handle_t h = get_global_handle(stream);
   if (!h) return Try::NotTaken;
   // src/cublas.cu:143-148 (with the threshold_n fix)
   if (!((unsigned long long)g.m >= h->intercept_threshold_m && (unsigned long long)g.n >= h->intercept_threshold_n &&
@@ -275,7 +283,7 @@ rocblas_status rocblas_create_handle(rocblas_handle *handle) {
     // the reference pre-sizes the workspace for a 1024^3 fp64_int8_9 GEMM here (src/cublas.cu:12-16, :109-110)
     const ozimmu_compute_mode_t mode = get_compute_mode();
     if (is_int8_mode(mode) || mode == OZIMMU_FP64_INT8_AUTO)
-      if (ozimmu_hip_handle_t h = get_global_handle())
+      if (ozimmu_hip_handle_t h = get_global_handle(nullptr))
         ozimmu_hip_reallocate_working_memory(
             h, ozimmu_hip_working_memory_size(OZIMMU_OP_N, OZIMMU_OP_N, 1024, 1024, 1024, OZIMMU_REAL,
                                               OZIMMU_FP64_INT8_9));

@@ -244,3 +244,49 @@ def test_pytorch_batched_matmul_is_intercepted():
     assert out.count("[CULiP Result][Dfp64_int8_10_stridedBatched-") == 1, out
     assert out.count("[CULiP Result][Zfp64_int8_10_stridedBatched-") == 1, out
     assert "-m1100-n1050-k1024-batch_count3]" in out or "-m1050-n1100-k1024-batch_count3]" in out, out
+
+
+def test_pytorch_cuda_graph_capture_through_the_preload():
+    """torch.cuda.graph around float64 matmuls under LD_PRELOAD: after an eager warm-up (workspace allocated) the captured
+    call is the Ozaki path's kernels (fp64_int8_3 is visibly coarse, so a replay that ran the vendor DGEMM would show);
+    a capture WITHOUT warm-up must not break (the shim captures the vendor GEMM for that call instead)"""
+    code = textwrap.dedent("""
+        import os, torch
+        torch.manual_seed(0)
+        a = torch.rand(1536, 1024, dtype=torch.float64, device="cuda") * 2 - 1
+        b = torch.rand(1024, 1280, dtype=torch.float64, device="cuda") * 2 - 1
+        ref = a.cpu() @ b.cpu()
+        out = torch.empty(1536, 1280, dtype=torch.float64, device="cuda")
+        s = torch.cuda.Stream()
+        # the vendor library itself cannot be captured cold (it allocates on first use): warm IT up in pass-through mode
+        os.environ["OZIMMU_COMPUTE_MODE"] = "dgemm"   # read on every call
+        with torch.cuda.stream(s):
+            torch.mm(a, b, out=out)
+        torch.cuda.synchronize()
+        os.environ["OZIMMU_COMPUTE_MODE"] = "fp64_int8_3"
+        # 1) capture before the shim has a workspace -> it hands the call to the vendor GEMM inside the graph
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, stream=s):
+            torch.mm(a, b, out=out)
+        out.zero_(); g0.replay(); torch.cuda.synchronize()
+        cold = (out.cpu() - ref).abs().max().item()
+        # 2) eager warm-up on the capture stream, then capture: the Ozaki kernels are in the graph
+        with torch.cuda.stream(s):
+            torch.mm(a, b, out=out)
+        torch.cuda.synchronize()
+        eager = out.clone()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=s):
+            torch.mm(a, b, out=out)
+        out.zero_(); g1.replay(); torch.cuda.synchronize()
+        warm = (out.cpu() - ref).abs().max().item()
+        same = torch.equal(out.view(torch.int64), eager.view(torch.int64))
+        print("RESULT %.3e %.3e %d" % (cold, warm, int(same)))
+    """)
+    e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
+    e.update(LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_3")
+    p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr
+    cold, warm, same = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0].split()[1:]
+    assert float(cold) < 1e-11, cold          # the vendor DGEMM was captured
+    assert float(warm) > 1e-6 and same == "1"  # the 3-slice Ozaki product was captured and replays bit for bit
