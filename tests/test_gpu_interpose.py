@@ -117,7 +117,26 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < zC.size(); i++) { C[i] = zd[2 * i]; imag = fmax(imag, fabs(zd[2 * i + 1])); }
     printf("RESIDUAL zgemm_64 %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb) + imag);
   }
+  // 6. the application switches to a new stream and destroys the old one (the shim must not touch the dead stream),
+  //    then destroys its BLAS handle (the shim's per-device state goes with the last one) and starts over
+  hipStream_t st2; hipStreamCreate(&st2); rocblas_set_stream(h, st2);
+  hipStreamSynchronize(st); hipStreamDestroy(st);
+  hipMemcpy(dC, C0.data(), C.size() * 8, hipMemcpyHostToDevice);
+  if (rocblas_dgemm(h, oa, ob, m, n, k, &alpha, dA, lda, dB, ldb, &beta, dC, m) != rocblas_status_success) return 9;
+  hipStreamSynchronize(st2);
+  hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
+  printf("RESIDUAL dgemm_after_stream_destroy %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
   rocblas_destroy_handle(h);
+  hipStreamDestroy(st2);
+  rocblas_handle h2;
+  if (rocblas_create_handle(&h2) != rocblas_status_success) return 10;
+  hipStream_t st3; hipStreamCreate(&st3); rocblas_set_stream(h2, st3);
+  hipMemcpy(dC, C0.data(), C.size() * 8, hipMemcpyHostToDevice);
+  if (rocblas_dgemm(h2, oa, ob, m, n, k, &alpha, dA, lda, dB, ldb, &beta, dC, m) != rocblas_status_success) return 11;
+  hipStreamSynchronize(st3);
+  hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
+  printf("RESIDUAL dgemm_after_handle_recreate %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  rocblas_destroy_handle(h2);
   return 0;
 }
 """
@@ -150,7 +169,8 @@ def test_preloaded_rocblas_dgemm_runs_the_ozaki_path(driver, ta, tb):
     assert all(v < 1e-14 for v in native.values())
     oz, out = run(driver, [512, ta, tb], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_9",
                   OZIMMU_INFO=1, OZIMMU_ENABLE_CULIP_PROFILING=1, **thr)
-    assert set(oz) == {"dgemm", "gemm_ex", "strided_batched", "strided_batched_ex", "dgemm_64", "zgemm_64"}
+    assert set(oz) == {"dgemm", "gemm_ex", "strided_batched", "strided_batched_ex", "dgemm_64", "zgemm_64",
+                       "dgemm_after_stream_destroy", "dgemm_after_handle_recreate"}
     assert all(v < 1e-15 for v in oz.values()), oz           # the reference's gate, through the preload
     assert "[ozIMMU LOG] Reallocated memory" in out           # src/handle.cu:69
     # CULiP line format of src/cublas.cu:157-162 / src/culip.cu:19-39
