@@ -19,6 +19,7 @@ DRIVER = r"""
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 // C = alpha*op(A)*op(B) + beta*C through rocblas_dgemm / rocblas_gemm_ex / strided batched, checked against a
 // long double host reference on sampled entries; prints "RESIDUAL <which> <value>".
@@ -136,6 +137,33 @@ int main(int argc, char** argv) {
   hipStreamSynchronize(st3);
   hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
   printf("RESIDUAL dgemm_after_handle_recreate %.3e\n", residual(A, B, C0, C, m, n, k, alpha, beta, ta, tb));
+  // 7. two host threads, each with its own BLAS handle and stream, hammer the shim's shared per-device state
+  {
+    double *dC2[2];
+    std::vector<double> Cs[2];
+    int bad = 0;
+    auto worker = [&](int t) {
+      rocblas_handle ht; hipStream_t stt;
+      if (rocblas_create_handle(&ht) != rocblas_status_success) { bad = 1; return; }
+      hipStreamCreate(&stt); rocblas_set_stream(ht, stt);
+      for (int it = 0; it < 6; it++) {
+        hipMemcpyAsync(dC2[t], C0.data(), C0.size() * 8, hipMemcpyHostToDevice, stt);
+        if (rocblas_dgemm(ht, oa, ob, m, n, k, &alpha, dA, lda, dB, ldb, &beta, dC2[t], m) != rocblas_status_success) bad = 1;
+      }
+      hipStreamSynchronize(stt);
+      Cs[t].resize(C0.size());
+      hipMemcpy(Cs[t].data(), dC2[t], C0.size() * 8, hipMemcpyDeviceToHost);
+      rocblas_destroy_handle(ht); hipStreamDestroy(stt);
+    };
+    for (int t = 0; t < 2; t++) hipMalloc(&dC2[t], C0.size() * 8);
+    rocblas_handle keep; rocblas_create_handle(&keep);   // keeps the shim's state alive while the workers come and go
+    std::thread t0(worker, 0), t1(worker, 1);
+    t0.join(); t1.join();
+    rocblas_destroy_handle(keep);
+    if (bad) return 12;
+    printf("RESIDUAL dgemm_two_threads %.3e\n",
+           fmax(residual(A, B, C0, Cs[0], m, n, k, alpha, beta, ta, tb), residual(A, B, C0, Cs[1], m, n, k, alpha, beta, ta, tb)));
+  }
   rocblas_destroy_handle(h2);
   return 0;
 }
@@ -149,7 +177,7 @@ def driver(tmp_path_factory):
     src.write_text(DRIVER)
     exe = d / "driver"
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(src), "-o",
-                           str(exe), "-L/opt/rocm/lib", "-lrocblas", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+                           str(exe), "-L/opt/rocm/lib", "-lrocblas", "-lamdhip64", "-pthread", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -170,7 +198,7 @@ def test_preloaded_rocblas_dgemm_runs_the_ozaki_path(driver, ta, tb):
     oz, out = run(driver, [512, ta, tb], LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_9",
                   OZIMMU_INFO=1, OZIMMU_ENABLE_CULIP_PROFILING=1, **thr)
     assert set(oz) == {"dgemm", "gemm_ex", "strided_batched", "strided_batched_ex", "dgemm_64", "zgemm_64",
-                       "dgemm_after_stream_destroy", "dgemm_after_handle_recreate"}
+                       "dgemm_after_stream_destroy", "dgemm_after_handle_recreate", "dgemm_two_threads"}
     assert all(v < 1e-15 for v in oz.values()), oz           # the reference's gate, through the preload
     assert "[ozIMMU LOG] Reallocated memory" in out           # src/handle.cu:69
     # CULiP line format of src/cublas.cu:157-162 / src/culip.cu:19-39
