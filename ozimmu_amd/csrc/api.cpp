@@ -258,8 +258,10 @@ static bool zero_phase_lines(ozimmu_hip_handle_t h, uint32_t *phase) {
 // The per-XCD phase hints and the tile queues of the persistent wide kernel only pay for problems with more tiles than
 // CUs; below that the launch is one tile per workgroup (K-split kernel, or a single round of the classic / wide kernel)
 // and the call saves the zeroing launch: three launches per small DGEMM (row maxima, cut, GEMM).
-static bool wants_phase(size_t m, size_t n, size_t batch) {
-  return batch == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) && m * n >= (size_t)2560 * 1024;
+// Nor for a short K: with fewer than 32 k-steps per tile the claim of a tile and the read of the hint cost more than
+// stealing and phase alignment return (8192^2 x 128..512: 3-6 % slower with them, tools/ab_short_k.py).
+static bool wants_phase(size_t m, size_t n, size_t k, size_t batch) {
+  return batch == 1 && !env_enabled("OZIMMU_HIP_NO_PHASE_HINT", false) && m * n >= (size_t)2560 * 1024 && k >= 1024;
 }
 
 // Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
@@ -339,7 +341,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  const bool use_phase = wants_phase(m, n, bs.count);
+  const bool use_phase = wants_phase(m, n, k, bs.count);
   if (use_phase && !zero_phase_lines(h, w.phase)) return 3;
   if (one_pass_split(8 * (m + n) * k * bs.count)) {
     // both operands (and every matrix of the batch) in one launch
@@ -475,7 +477,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
 
   const bool prof = h->profiling;
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
-  const bool use_phase = wants_phase(m, n, bs.count);
+  const bool use_phase = wants_phase(m, n, k, bs.count);
   if (use_phase && !zero_phase_lines(h, w.phase)) return 3;
   if (one_pass_split(16 * (m + n) * k * bs.count)) {
     const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, nullptr},

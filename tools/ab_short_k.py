@@ -1,0 +1,25 @@
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+import ozimmu_amd as oz
+h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
+mn = 8192
+for k in (128, 256, 512):
+    a = torch.rand(k, mn, dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand(k, mn, dtype=torch.float64, device="cuda") * 2 - 1
+    c = torch.zeros(mn, mn, dtype=torch.float64, device="cuda")
+    out = []
+    for name, env in (("default", {}), ("no hint", {"OZIMMU_HIP_NO_PHASE_HINT": "1"}), ("classic", {"OZIMMU_HIP_GEMM_KERNEL": "classic"}),
+                      ("classic no hint", {"OZIMMU_HIP_GEMM_KERNEL": "classic", "OZIMMU_HIP_NO_PHASE_HINT": "1"}),
+                      ("wide", {"OZIMMU_HIP_GEMM_KERNEL": "wide"}), ("wide static", {"OZIMMU_HIP_GEMM_KERNEL": "wide", "OZIMMU_HIP_WIDE_STATIC": "1"}),
+                      ("wide no hint", {"OZIMMU_HIP_GEMM_KERNEL": "wide", "OZIMMU_HIP_NO_PHASE_HINT": "1"})):
+        for kk in ("OZIMMU_HIP_NO_PHASE_HINT", "OZIMMU_HIP_GEMM_KERNEL", "OZIMMU_HIP_WIDE_STATIC"): os.environ.pop(kk, None)
+        os.environ.update(env)
+        def call(): assert oz.gemm(h, "N", "T", mn, mn, k, -1.0, a, mn, b, mn, 1.0, c, mn, "fp64_int8_9") == 0
+        best = 1e9
+        for r in range(2):
+            for _ in range(3): call()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20): call()
+            torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 20 * 1e6)
+        out.append(f"{name} {best:7.1f}")
+    print(f"k={k}: " + " | ".join(out), flush=True)
