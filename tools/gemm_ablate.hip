@@ -115,7 +115,10 @@ static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEv
 int main(int argc, char **argv) {
   const size_t N = argc > 1 ? std::atol(argv[1]) : 8192;
   const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
-  constexpr int S = 9;
+#ifndef ABLATE_S
+#define ABLATE_S 9
+#endif
+  constexpr int S = ABLATE_S; // -DABLATE_S=8: the schedule parameters at another slice count
   const size_t M = argc > 4 ? std::atol(argv[4]) : N, K = argc > 5 ? std::atol(argv[5]) : N;
   const size_t pa = tiled_plane_bytes(M, K, S), pb = tiled_plane_bytes(N, K, S);
   int8_t *A, *B;
@@ -167,7 +170,35 @@ int main(int argc, char **argv) {
     bool nophase;
     std::vector<float> ms;
   };
-#ifdef ABLATE_SMALL_TILES // -DABLATE_SMALL_TILES: the 64x128 / 32x128 forms of the wide kernel (problems of ~2 tiles per CU)
+#ifdef ABLATE_SCHEDULE // -DABLATE_SCHEDULE [-DABLATE_S=n -DABLATE_WA=w]: copy spacing / barrier position of the wide kernel's k-step
+#ifndef ABLATE_WA
+#define ABLATE_WA 3
+#endif
+  constexpr int W = ABLATE_WA;
+  std::vector<Var> vars = {
+      {"shipped: dma every 4, tail 6", run_w<S, W, 0, 0, -1, 4, 6, true, true>, false, {}},
+      {"dma every 3, tail 6", run_w<S, W, 0, 0, -1, 3, 6, true, true>, false, {}},
+      {"dma every 2, tail 6", run_w<S, W, 0, 0, -1, 2, 6, true, true>, false, {}},
+      {"dma every 5, tail 6", run_w<S, W, 0, 0, -1, 5, 6, true, true>, false, {}},
+      {"dma every 4, tail 4", run_w<S, W, 0, 0, -1, 4, 4, true, true>, false, {}},
+      {"dma every 4, tail 8", run_w<S, W, 0, 0, -1, 4, 8, true, true>, false, {}},
+      {"dma every 4, tail 5", run_w<S, W, 0, 0, -1, 4, 5, true, true>, false, {}},
+      {"pd2, dma every 4, tail 6", run_w<S, W, VARW_NA3, 0, -1, 4, 6, true, true>, false, {}},
+      {"mfma only", run_w<S, W, VARW_MFMA_ONLY, 0, -1, 4, 6, true, true>, false, {}},
+  };
+  for (int r = 0; r < rounds + 1; r++)
+    for (auto &v : vars) {
+      const float ms = v.fn(a, st, e0, e1);
+      if (r > 0) v.ms.push_back(ms);
+    }
+  for (auto &v : vars) {
+    std::sort(v.ms.begin(), v.ms.end());
+    const double ops = (double)(S * (S + 1) / 2) * 2.0 * M * N * K;
+    printf("S=%d WA=%d %s median %8.3f ms (%7.1f TOPS)   min %8.3f ms\n", S, W, v.name, v.ms[v.ms.size() / 2],
+           ops / v.ms[v.ms.size() / 2] / 1e9, v.ms[0]);
+  }
+  return 0;
+#elif defined(ABLATE_SMALL_TILES) // -DABLATE_SMALL_TILES: the 64x128 / 32x128 forms of the wide kernel (problems of ~2 tiles per CU)
   std::vector<Var> vars = {
       {"wide 64x128 persistent dma every 4 (shipped)", run_w<S, 2, 0, 0, -1, 4, 6, false, true>, false, {}},
       {"wide 64x128 persistent dma every 3", run_w<S, 2, 0, 0, -1, 3, 6, false, true>, false, {}},
