@@ -408,7 +408,10 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
 // kernel needs ~100 instead of 186 registers, i.e. 4 instead of 2 waves per SIMD for BOTH layouts of the launch)
 template <bool PF, bool LOW = true>
 __global__ __launch_bounds__(256) void cut_multi_kernel(const SplitJobs jobs) {
-  __shared__ double tiles[4][32][33];
+  // the transpose tiles of the k-contiguous path: dynamic, so that a launch with row-contiguous views only (N/T products:
+  // panel updates) allocates none and is not held to four workgroups per CU by 33 KiB of LDS it never touches
+  extern __shared__ __attribute__((aligned(16))) double tiles_dyn[];
+  double(*tiles)[32][33] = reinterpret_cast<double(*)[32][33]>(tiles_dyn);
   int ji = 0;
   uint32_t blk = blockIdx.x;
 #pragma unroll
@@ -469,14 +472,18 @@ hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStr
   }
   if (total == 0 || batch == 0) return hipSuccess;
   if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  bool prefetch = false;
-  for (int i = 0; i < count; i++) prefetch = prefetch || (jobs.nblk[i] && jobs.nx[i] > 1);
+  bool prefetch = false, any_kcontig = false;
+  for (int i = 0; i < count; i++) {
+    prefetch = prefetch || (jobs.nblk[i] && jobs.nx[i] > 1);
+    any_kcontig = any_kcontig || (jobs.nblk[i] && job[i].v.stride_k < job[i].v.stride_r);
+  }
+  const size_t lds = any_kcontig ? sizeof(double) * 4 * 32 * 33 : 0;
   if (prefetch)
-    hipLaunchKernelGGL(cut_multi_kernel<true>, dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+    hipLaunchKernelGGL(cut_multi_kernel<true>, dim3((unsigned)total, 1, batch), dim3(256), lds, stream, jobs);
   else if (S * L > 64)
-    hipLaunchKernelGGL((cut_multi_kernel<false, true>), dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+    hipLaunchKernelGGL((cut_multi_kernel<false, true>), dim3((unsigned)total, 1, batch), dim3(256), lds, stream, jobs);
   else // every slice in the upper 64 bits of the shifted mantissa (up to fp64_int8_9 at L = 7): the lean form
-    hipLaunchKernelGGL((cut_multi_kernel<false, false>), dim3((unsigned)total, 1, batch), dim3(256), 0, stream, jobs);
+    hipLaunchKernelGGL((cut_multi_kernel<false, false>), dim3((unsigned)total, 1, batch), dim3(256), lds, stream, jobs);
   return hipGetLastError();
 }
 
