@@ -243,6 +243,9 @@ static bool exp_words(ozimmu_hip_handle_t h, size_t m, size_t n, int parts, size
   }
   x.tag = h->exp_epoch << 11;
   char *base = reinterpret_cast<char *>(h->exp_words);
+  // A call that is being captured into a graph will be replayed later with THIS tag, after other calls have left words of
+  // later epochs (or an earlier replay words of the same one) in the buffer: the graph zeroes its words itself.
+  if (stream_is_capturing(h->stream) && !hip_ok(launch_zero_words(base, bytes, 0, 1, h->stream), "zero_words")) return false;
   for (int i = 0; i < parts; i++) {
     x.a[i] = reinterpret_cast<uint32_t *>(base + (size_t)i * ea);
     x.b[i] = reinterpret_cast<uint32_t *>(base + (size_t)parts * ea + (size_t)i * eb);

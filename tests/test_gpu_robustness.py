@@ -355,6 +355,26 @@ def test_gemm_is_capturable_into_a_graph_once_the_workspace_exists(oz):
             g1.replay()
             torch.cuda.synchronize()
             np.testing.assert_array_equal(c.cpu().numpy().view(np.uint64), c_ref.buf.view(np.uint64))
+        # 3) the graph is replayed on NEW data after other calls have used the handle: the split's row-exponent words
+        #    carry a per-call epoch, and the replay runs with the epoch of capture time -- it must neither see the later
+        #    calls' words nor its own earlier maxima (the new A is 2^-20 times smaller: a stale maximum would shift every
+        #    slice)
+        other = operand("T", 500, 300, rng)
+        other_b = operand("N", 300, 410, rng)
+        c_other = torch.zeros(410, 500, dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(s):
+            assert m_.gemm_on_stream(h, s, "T", "N", 500, 410, 300, 1.0, other.dev, other.ld, other_b.dev, other_b.ld, 0.0,
+                                     c_other, 500, "fp64_int8_11") == 0
+        torch.cuda.synchronize()
+        a.buf[...] *= 2.0 ** -20
+        a.buf[:, 5] = 0.0
+        a.dev.copy_(torch.from_numpy(a.buf))
+        c_ref2 = ColMajor(m, n)
+        assert O.gemm("N", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref2.view, S, O.ORDER_DIAGONAL) == 0
+        c.fill_(float("nan"))
+        g1.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(c.cpu().numpy().view(np.uint64), c_ref2.buf.view(np.uint64))
     finally:
         torch.cuda.synchronize()
         m_.destroy(h)
