@@ -223,7 +223,10 @@ static bool exp_words(ozimmu_hip_handle_t h, size_t m, size_t n, int parts, size
   const size_t bytes = x.pitch * std::max<size_t>(count, 1);
   if (bytes > h->exp_words_bytes) {
     if (stream_is_capturing(h->stream)) return false; // allocation is illegal while the stream is captured into a graph
-    if (h->exp_words) hipFree(h->exp_words);          // device-synchronising: earlier calls are done with it
+    if (h->exp_words && h->seen_capture)
+      h->retired_blocks.push_back(h->exp_words); // a captured graph may still point into it (handle.h)
+    else if (h->exp_words)
+      hipFree(h->exp_words); // device-synchronising: earlier calls are done with it
     h->exp_words = nullptr;
     h->exp_words_bytes = 0;
     const size_t cap = std::max<size_t>(bytes, (size_t)1 << 20);
@@ -245,7 +248,10 @@ static bool exp_words(ozimmu_hip_handle_t h, size_t m, size_t n, int parts, size
   char *base = reinterpret_cast<char *>(h->exp_words);
   // A call that is being captured into a graph will be replayed later with THIS tag, after other calls have left words of
   // later epochs (or an earlier replay words of the same one) in the buffer: the graph zeroes its words itself.
-  if (stream_is_capturing(h->stream) && !hip_ok(launch_zero_words(base, bytes, 0, 1, h->stream), "zero_words")) return false;
+  if (stream_is_capturing(h->stream)) {
+    h->seen_capture = true;
+    if (!hip_ok(launch_zero_words(base, bytes, 0, 1, h->stream), "zero_words")) return false;
+  }
   for (int i = 0; i < parts; i++) {
     x.a[i] = reinterpret_cast<uint32_t *>(base + (size_t)i * ea);
     x.b[i] = reinterpret_cast<uint32_t *>(base + (size_t)parts * ea + (size_t)i * eb);
@@ -669,6 +675,7 @@ int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
     if (h->working_memory_ptr) hipFree(h->working_memory_ptr);
     if (h->d_mantissa_loss_counter_ptr) hipFree(h->d_mantissa_loss_counter_ptr);
     if (h->exp_words) hipFree(h->exp_words);
+    for (void *p : h->retired_blocks) hipFree(p);
     for (auto &e : h->ev)
       if (e) hipEventDestroy(e);
     if (h->tail_ev) hipEventDestroy(h->tail_ev);
@@ -735,7 +742,9 @@ size_t ozimmu_hip_reallocate_working_memory(ozimmu_hip_handle_t h, size_t size_i
   if (h->working_memory_ptr) {
     // kernels already enqueued on the stream still use the old block: release it in stream order
     // (hipFree would device-synchronise, src/handle.cu:71-75 does exactly that)
-    if (h->malloc_mode == OZIMMU_MALLOC_SYNC)
+    if (h->seen_capture)
+      h->retired_blocks.push_back(h->working_memory_ptr); // a captured graph may still point into it (handle.h)
+    else if (h->malloc_mode == OZIMMU_MALLOC_SYNC)
       hipFree(h->working_memory_ptr);
     else
       hipFreeAsync(h->working_memory_ptr, h->stream);

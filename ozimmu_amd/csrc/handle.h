@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/ozimmu_hip.h"
 
@@ -28,6 +29,12 @@ struct ozimmu_hip_handle {
   uint32_t *exp_words = nullptr;
   size_t exp_words_bytes = 0;
   uint32_t exp_epoch = 0;
+
+  // Once a call of this handle has been captured into a graph, the graph holds pointers into the workspace and the
+  // exponent-word buffer of that moment: blocks that are outgrown later are kept until the handle is destroyed instead of
+  // freed, so that a replay never touches released memory.
+  bool seen_capture = false;
+  std::vector<void *> retired_blocks;
   double avg_mantissa_loss_threshold = 0; // src/handle.hpp:26
 
   // src/handle.hpp:28-30, read at creation (src/handle.cu:25-30)

@@ -375,6 +375,20 @@ def test_gemm_is_capturable_into_a_graph_once_the_workspace_exists(oz):
         g1.replay()
         torch.cuda.synchronize()
         np.testing.assert_array_equal(c.cpu().numpy().view(np.uint64), c_ref2.buf.view(np.uint64))
+        # 4) a much larger eager call outgrows the workspace the graph points into: the old block must stay alive
+        big_a = torch.rand(1500, 1400, dtype=torch.float64, device="cuda")
+        big_b = torch.rand(1300, 1500, dtype=torch.float64, device="cuda")
+        big_c = torch.zeros(1300, 1400, dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(s):
+            assert m_.gemm_on_stream(h, s, "N", "N", 1400, 1300, 1500, 1.0, big_a, 1400, big_b, 1500, 0.0, big_c, 1400,
+                                     "fp64_int8_12") == 0
+        torch.cuda.synchronize()
+        junk = [torch.full((1 << 22,), 3.0, dtype=torch.float64, device="cuda") for _ in range(4)]  # reuse freed memory, if any
+        c.fill_(float("nan"))
+        g1.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(c.cpu().numpy().view(np.uint64), c_ref2.buf.view(np.uint64))
+        assert all(float(j.min()) == 3.0 and float(j.max()) == 3.0 for j in junk)  # the replay wrote into its own memory
     finally:
         torch.cuda.synchronize()
         m_.destroy(h)
