@@ -348,7 +348,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   ba.exps_stride = bb.exps_stride = xw.pitch;
   ba.tag = bb.tag = xw.tag;
 
-  const bool prof = h->profiling;
+  const bool prof = h->profiling && !stream_is_capturing(h->stream); // the stage timer synchronises on its events
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
   const bool use_phase = wants_phase(m, n, k, bs.count);
   if (use_phase && !zero_phase_lines(h, w.phase)) return 3;
@@ -484,7 +484,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   ba.exps_stride = bb.exps_stride = xw.pitch;
   ba.tag = bb.tag = xw.tag;
 
-  const bool prof = h->profiling;
+  const bool prof = h->profiling && !stream_is_capturing(h->stream); // the stage timer synchronises on its events
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
   const bool use_phase = wants_phase(m, n, k, bs.count);
   if (use_phase && !zero_phase_lines(h, w.phase)) return 3;
