@@ -791,6 +791,7 @@ int ozimmu_hip_native_dgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozim
   if (!create || !set_stream || !dgemm) return (int)rocblas_status_internal_error;
   std::lock_guard<std::recursive_mutex> lock(h->mtx); // lazy private handle + its stream are per-handle state
   if (!h->rocblas_handle) {
+    if (stream_is_capturing(h->stream)) return (int)rocblas_status_internal_error; // creating it allocates device memory
     rocblas_handle rh = nullptr;
     const rocblas_status st = create(&rh);
     if (st != rocblas_status_success) return (int)st;
@@ -818,6 +819,7 @@ static int native_zgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_o
   if (!create || !set_stream || !zgemm) return (int)rocblas_status_internal_error;
   std::lock_guard<std::recursive_mutex> lock(h->mtx);
   if (!h->rocblas_handle) {
+    if (stream_is_capturing(h->stream)) return (int)rocblas_status_internal_error; // creating it allocates device memory
     rocblas_handle rh = nullptr;
     const rocblas_status st = create(&rh);
     if (st != rocblas_status_success) return (int)st;
@@ -856,6 +858,7 @@ int ozimmu_hip_gemm_f32(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_o
   if (!create || !set_stream || !sgemm || !cgemm) return 3;
   std::lock_guard<std::recursive_mutex> lock(h->mtx);
   if (!h->rocblas_handle) {
+    if (stream_is_capturing(h->stream)) return 3; // creating it allocates device memory: not while capturing a graph
     rocblas_handle rh = nullptr;
     if (create(&rh) != rocblas_status_success) return 3;
     h->rocblas_handle = rh;
