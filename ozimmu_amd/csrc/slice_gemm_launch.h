@@ -121,13 +121,20 @@ template <int S, int D0, int ND>
 struct WideCfg {
   static constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
   static constexpr bool regs_ok(int wa) { return wa * ND * 16 + SL * 4 + 16 + 14 <= 512; }
-  static constexpr size_t lds(int wa, int na) { return (size_t)(na * wa + 8) * SL * FRAG_BYTES; }
+  // nb: wave-private B buffers (2, or 1 with VARW_B1: slice_gemm_w_kernel.h)
+  static constexpr size_t lds(int wa, int na, int nb = 2) { return (size_t)(na * wa + 4 * nb) * SL * FRAG_BYTES; }
   static constexpr size_t LDS_MAX = 160 * 1024;
-  static constexpr int WA = (regs_ok(4) && lds(4, 2) <= LDS_MAX)   ? 4
-                            : (regs_ok(3) && lds(3, 2) <= LDS_MAX) ? 3
-                            : (regs_ok(2) && lds(2, 2) <= LDS_MAX) ? 2
-                            : (regs_ok(1) && lds(1, 2) <= LDS_MAX) ? 1 // 14..16 staged slices (second pass of S = 14..16)
-                                                                   : 0;
+  static constexpr int pick(int nb) {
+    return (regs_ok(4) && lds(4, 2, nb) <= LDS_MAX)   ? 4
+           : (regs_ok(3) && lds(3, 2, nb) <= LDS_MAX) ? 3
+           : (regs_ok(2) && lds(2, 2, nb) <= LDS_MAX) ? 2
+           : (regs_ok(1) && lds(1, 2, nb) <= LDS_MAX) ? 1
+                                                      : 0;
+  }
+  // two B buffers wherever they leave room for tiles of 64+ rows (every single pass, every first pass); the second pass
+  // of S = 14..18 stages 14-18 slices: one B buffer there (64x128 tiles instead of 32x128 / the classic kernel)
+  static constexpr int NB = pick(2) >= 2 ? 2 : (pick(1) > pick(2) ? 1 : 2);
+  static constexpr int WA = pick(NB);
   static constexpr int NA = 2;
   static constexpr bool ok = WA >= 1;
 };
@@ -206,8 +213,8 @@ static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu, int staged_sli
 template <int S, int D0, int ND>
 static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipStream_t stream) {
   using Cfg = WideCfg<S, D0, ND>;
-  constexpr int VARW = Cfg::NA == 3 ? VARW_NA3 : 0;
-  constexpr size_t lds = Cfg::lds(Cfg::WA, Cfg::NA);
+  constexpr int VARW = (Cfg::NA == 3 ? VARW_NA3 : 0) | (Cfg::NB == 1 ? VARW_B1 : 0);
+  constexpr size_t lds = Cfg::lds(Cfg::WA, Cfg::NA, Cfg::NB);
   SliceGemmArgs a = a0;
   a.tiles_m = pl.n_big;
   a.tiles_m2 = pl.n_small;
@@ -279,7 +286,7 @@ static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
                               (loop_us < (SL >= 11 ? 15.0 : SL == 10 ? 30.0 : 40.0) ||
                                (SL < 8 && pl.efficiency < (SL <= 5 ? 0.9 : 0.62)));
     if constexpr (WideCfg<S, D0, ND>::ok)
-      if (!classic_wins && (second_pass || prefer_wide(pl, (a.N + 127) / 128, ncu_eff, SL)))
+      if (!classic_wins && ((second_pass && !getenv("OZIMMU_HIP_GEMM_KERNEL")) || prefer_wide(pl, (a.N + 127) / 128, ncu_eff, SL)))
         return launch_wide<S, D0, ND>(a, pl, stream);
   }
   return launch_one<S, D0, ND, FORCE_WM>(a, stream);

@@ -114,6 +114,7 @@ constexpr int VARW_NA3 = 1;        // 3 A buffers (prefetch distance 2); else 2 
 constexpr int VARW_NO_GLOBAL = 2;  // ablation: no staging (LDS holds garbage)
 constexpr int VARW_MFMA_ONLY = 4;  // ablation: no LDS reads either
 constexpr int VARW_NO_EPILOGUE = 128; // measurement: accumulators are only kept alive, nothing is converted or stored
+constexpr int VARW_B1 = 1024;      // ONE wave-private B buffer instead of two (see w_tile): passes with 14+ staged slices
 constexpr int VARW_EPI_NOSTORE = 256; // measurement: epilogue without its stores
 constexpr int VARW_EPI_NOCHAIN = 512; // measurement: epilogue without its FP64 chains
 constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..107 of the first 32 workgroups -> p.acc
@@ -130,6 +131,13 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   constexpr int A_STAGE = WA * SL * FRAG_BYTES;    // shared
   constexpr int B_STAGE = 4 * SL * FRAG_BYTES;     // 4 wave-private runs of SL blocks
   constexpr int OFF_B = NA * A_STAGE;
+  // B buffers per wave.  A wave holds ALL B fragments of a k-step in registers from the end of the previous step on (they
+  // are consumed by the step's first group, j descending, before the first copy of the next stage is issued at slot
+  // DMA0 = the first slot of group 1), so the next stage's B may land in the very buffer the current one came from: one
+  // buffer is enough at prefetch distance 1.  The shipped configurations keep two (unchanged timing); VARW_B1 is what
+  // lets the second diagonal pass of S = 14..18 (14-18 staged slices) use 64x128 tiles in 160 KiB.
+  constexpr int NB = (VARW & VARW_B1) ? 1 : 2;
+  static_assert(NB == 2 || PD == 1, "a single B buffer needs prefetch distance 1");
   constexpr int NQA = (WA * SL + 3) / 4;           // A blocks copied per wave per stage
   constexpr int NDMA = NQA + SL;                   // copies per wave per stage
   constexpr int R = 4;                             // A fragment ring (registers)
@@ -292,7 +300,7 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
 #pragma unroll
   for (int d = 0; d < PD; d++) {
     if ((uint32_t)d < nk) {
-      static_for<NDMA>([&](auto cc) { copy_n(cc, d % NA, d % 2, k_issue); });
+      static_for<NDMA>([&](auto cc) { copy_n(cc, d % NA, NB == 1 ? 0 : d % 2, k_issue); });
       k_issue = koff_next(k_issue);
       issued++;
     }
@@ -328,12 +336,12 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
     if constexpr (TRACE) ts[5] = stamp();
     const int abuf_n = abuf + 1 == NA ? 0 : abuf + 1;                        // next stage
     const int abuf_pf = (PD == 1) ? abuf_n : (abuf_n + 1 == NA ? 0 : abuf_n + 1); // stage PD ahead
-    const int bbuf_pf = (PD == 1) ? (bbuf ^ 1) : bbuf;
+    const int bbuf_pf = NB == 1 ? 0 : (PD == 1) ? (bbuf ^ 1) : bbuf;
     const uint32_t kb_pf = k_issue; // k-step (relative to the pass) of the stage being prefetched
     if constexpr (PF) k_issue = koff_next(k_issue);
     const char *la = la0 + abuf * A_STAGE;
     const char *la_n = la0 + abuf_n * A_STAGE;
-    const char *lb_n = lb0 + (bbuf ^ 1) * B_STAGE;
+    const char *lb_n = lb0 + (NB == 1 ? 0 : (bbuf ^ 1) * B_STAGE);
     static_for<NS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       constexpr int g = SC.sg[s];
