@@ -192,10 +192,14 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
   auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kstep) {
     constexpr int c = decltype(cc)::value;
     const uint32_t voff = lane_off + kstep * (uint32_t)(S * FRAG_BYTES);
-    if constexpr (c < NQA)
+    if constexpr (c < NQA) {
       copy_a(c, voff, lds0 + abuf * A_STAGE);
-    else
+    } else {
+      // one B buffer: the copy overwrites what the current step's B fragments were read from.  Those reads were issued a
+      // step's tail ago and have long returned; the wait makes that a guarantee instead of a timing argument.
+      if constexpr (NB == 1 && c == NQA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       copy_b(std::integral_constant<int, c - NQA>{}, voff, ldsb0 + bbuf * B_STAGE);
+    }
   };
 
   // ---- accumulators: WA*ND x 16 registers, placed by hand ---------------------------------------------------------
