@@ -162,7 +162,7 @@ static int check_address_alignment(const void *p, size_t elem, const char *mat) 
 // with 64 MiB bands it LOSES (8192^3: 16.90 vs 16.69 ms per GEMM, 6144^3: 7.34 vs 7.22: more, smaller launches cost more
 // than the cache hits return), so the default is one band; the knob stays for experiments and the parity tests.
 static bool run_split(ozimmu_hip_handle_t h, const OperandView &v, uint32_t *exps, int S, int L,
-                      int8_t *planes, double *max_exp, const Batch &batch = Batch()) {
+                      int8_t *planes, double *max_exp, const Batch &batch = Batch(), bool have_row_max = false) {
   size_t band_bytes = 0;
   if (const char *e = getenv("OZIMMU_HIP_SPLIT_BAND_BYTES")) band_bytes = std::strtoull(e, nullptr, 10);
   const size_t row_bytes = 8 * std::max<size_t>(v.K, 1) * std::max<uint32_t>(batch.count, 1);
@@ -174,7 +174,7 @@ static bool run_split(ozimmu_hip_handle_t h, const OperandView &v, uint32_t *exp
     b.in = v.in + r0 * v.stride_r;
     b.rows = std::min(band_rows, v.rows - r0);
     int8_t *pl = planes + (r0 / FRAG_ROWS) * KB * (size_t)S * FRAG_BYTES;
-    if (!hip_ok(launch_row_max_exp(b, exps + r0, h->stream, batch), "row_max_exp") ||
+    if ((!have_row_max && !hip_ok(launch_row_max_exp(b, exps + r0, h->stream, batch), "row_max_exp")) ||
         !hip_ok(launch_cut(b, exps + r0, S, L, pl, max_exp + r0, h->stream, batch), "cut"))
       return false;
   }
@@ -217,7 +217,26 @@ struct ExpWords {
   size_t pitch = 0; // bytes per matrix
   uint32_t tag = 0;
 };
+// pointers into the buffer for the CURRENT epoch (no new epoch): the layout exp_words() hands out
+static void exp_words_layout(ozimmu_hip_handle_t h, size_t m, size_t n, int parts, ExpWords &x) {
+  const size_t ea = align256(4 * m), eb = align256(4 * n);
+  x.pitch = (size_t)parts * (ea + eb);
+  x.tag = h->exp_epoch << 11;
+  char *base = reinterpret_cast<char *>(h->exp_words);
+  for (int i = 0; i < parts; i++) {
+    x.a[i] = reinterpret_cast<uint32_t *>(base + (size_t)i * ea);
+    x.b[i] = reinterpret_cast<uint32_t *>(base + (size_t)parts * ea + (size_t)i * eb);
+  }
+}
+// fp64_int8_auto (handle.h: ExpReuse): do the words of the current epoch already hold the row maxima of these operands?
+static bool exp_words_reusable(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m, size_t n,
+                               size_t k, const void *a, size_t lda, const void *b, size_t ldb, int parts, size_t count) {
+  const auto &r = h->exp_reuse;
+  return r.valid && count == 1 && r.a == a && r.b == b && r.lda == lda && r.ldb == ldb && r.m == m && r.n == n && r.k == k &&
+         r.op_a == (int)op_A && r.op_b == (int)op_B && r.parts == parts && !env_enabled("OZIMMU_HIP_NO_EXP_REUSE", false);
+}
 static bool exp_words(ozimmu_hip_handle_t h, size_t m, size_t n, int parts, size_t count, ExpWords &x) {
+  h->exp_reuse.valid = false; // a new epoch: whatever an earlier statistic pass left is history
   const size_t ea = align256(4 * m), eb = align256(4 * n);
   x.pitch = (size_t)parts * (ea + eb);
   const size_t bytes = x.pitch * std::max<size_t>(count, 1);
@@ -344,7 +363,14 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   bb.in_stride = bs.stride_b;
   ba.ws_stride = bb.ws_stride = slot;
   ExpWords xw;
-  if (!exp_words(h, m, n, 1, bs.count, xw)) return 3;
+  // fp64_int8_auto: the statistic pass that selected this mode has just computed these row maxima
+  const bool have_row_max = exp_words_reusable(h, op_A, op_B, m, n, k, a, lda, b, ldb, 1, bs.count);
+  if (have_row_max) {
+    exp_words_layout(h, m, n, 1, xw);
+    h->exp_reuse.valid = false;
+  } else if (!exp_words(h, m, n, 1, bs.count, xw)) {
+    return 3;
+  }
   ba.exps_stride = bb.exps_stride = xw.pitch;
   ba.tag = bb.tag = xw.tag;
 
@@ -363,13 +389,15 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
     // booked under split_A and the cut pass under split_B)
     const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, xw.a[0]},
                               {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, xw.b[0]}};
-    if (!hip_ok(launch_row_max_multi(jobs, 2, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "row_max_exp")) return 3;
+    if (!have_row_max &&
+        !hip_ok(launch_row_max_multi(jobs, 2, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "row_max_exp"))
+      return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
     if (!hip_ok(launch_cut_multi(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "cut")) return 3;
   } else {
-    if (!run_split(h, view_A(op_A, m, k, a, lda), xw.a[0], S, L, w.planes_a, w.ea, ba)) return 3;
+    if (!run_split(h, view_A(op_A, m, k, a, lda), xw.a[0], S, L, w.planes_a, w.ea, ba, have_row_max)) return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
-    if (!run_split(h, view_B(op_B, k, n, b, ldb), xw.b[0], S, L, w.planes_b, w.eb, bb)) return 3;
+    if (!run_split(h, view_B(op_B, k, n, b, ldb), xw.b[0], S, L, w.planes_b, w.eb, bb, have_row_max)) return 3;
   }
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
 
@@ -480,7 +508,13 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   bb.in_stride = 2 * bs.stride_b;
   ba.ws_stride = bb.ws_stride = slot;
   ExpWords xw;
-  if (!exp_words(h, m, n, 2, bs.count, xw)) return 3;
+  const bool have_row_max = exp_words_reusable(h, op_A, op_B, m, n, k, a, lda, b, ldb, 2, bs.count);
+  if (have_row_max) {
+    exp_words_layout(h, m, n, 2, xw);
+    h->exp_reuse.valid = false;
+  } else if (!exp_words(h, m, n, 2, bs.count, xw)) {
+    return 3;
+  }
   ba.exps_stride = bb.exps_stride = xw.pitch;
   ba.tag = bb.tag = xw.tag;
 
@@ -500,16 +534,18 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
                               {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, xw.a[1]},
                               {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, xw.b[0]},
                               {view_B_part(op_B, k, n, b, ldb, 1), w.planes_b[1], w.eb[1], bb.in_stride, xw.b[1]}};
-    if (!hip_ok(launch_row_max_multi(jobs, 4, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "row_max_exp")) return 3;
+    if (!have_row_max &&
+        !hip_ok(launch_row_max_multi(jobs, 4, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "row_max_exp"))
+      return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
     if (!hip_ok(launch_cut_multi(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot, xw.pitch, xw.tag), "cut")) return 3;
   } else {
     for (int part = 0; part < 2; part++)
-      if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), xw.a[part], S, L, w.planes_a[part], w.ea[part], ba))
+      if (!run_split(h, view_A_part(op_A, m, k, a, lda, part), xw.a[part], S, L, w.planes_a[part], w.ea[part], ba, have_row_max))
         return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
     for (int part = 0; part < 2; part++)
-      if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), xw.b[part], S, L, w.planes_b[part], w.eb[part], bb))
+      if (!run_split(h, view_B_part(op_B, k, n, b, ldb, part), xw.b[part], S, L, w.planes_b[part], w.eb[part], bb, have_row_max))
         return 3;
   }
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
@@ -911,24 +947,32 @@ static int mantissa_loss_impl(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, oz
   std::lock_guard<std::recursive_mutex> lock(h->mtx);
   const int L = (int)ozimmu_hip_get_bits_per_int8((uint32_t)k); // src/split.cu:461
   const int parts = cplx ? 2 : 1;
-  const size_t ea = align256(4 * m), eb = align256(4 * n), exps_bytes = parts * (ea + eb);
   if (stream_is_capturing(h->stream)) return 3; // the statistic is read back on the host: not capturable into a graph
   WorkspaceUse use(h);
-  if (!ensure_workspace(h, exps_bytes)) return 3;
-  char *base = (char *)h->working_memory_ptr;
-  bool ok = hip_ok(hipMemsetAsync(base, 0, exps_bytes, h->stream), "memset") &&
-            hip_ok(hipMemsetAsync(h->d_mantissa_loss_counter_ptr, 0, 16 * sizeof(unsigned long long), h->stream),
+  // the row maxima go to the tagged exponent words, in the layout the GEMM that follows (fp64_int8_auto) will ask for:
+  // it finds them there and skips its own row-maximum pass (handle.h: ExpReuse)
+  ExpWords xw;
+  if (!exp_words(h, m, n, parts, 1, xw)) return 3;
+  Batch tagged;
+  tagged.tag = xw.tag;
+  bool ok = hip_ok(hipMemsetAsync(h->d_mantissa_loss_counter_ptr, 0, 16 * sizeof(unsigned long long), h->stream),
                    "memset"); // all 16 zeroed (src/split.cu:302-315 zeroes 8)
   for (int part = 0; part < parts && ok; part++) {
-    uint32_t *xa = (uint32_t *)(base + part * (ea + eb)), *xb = (uint32_t *)(base + part * (ea + eb) + ea);
+    uint32_t *xa = xw.a[part], *xb = xw.b[part];
     const OperandView va = cplx ? view_A_part(op_A, m, k, a, lda, part) : view_A(op_A, m, k, a, lda);
     const OperandView vb = cplx ? view_B_part(op_B, k, n, b, ldb, part) : view_B(op_B, k, n, b, ldb);
-    ok = hip_ok(launch_row_max_exp(va, xa, h->stream), "row_max_exp") &&
-         hip_ok(launch_row_max_exp(vb, xb, h->stream), "row_max_exp") &&
-         hip_ok(launch_mantissa_loss(va, xa, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss") &&
-         hip_ok(launch_mantissa_loss(vb, xb, L, h->d_mantissa_loss_counter_ptr, h->stream), "loss");
+    ok = hip_ok(launch_row_max_exp(va, xa, h->stream, tagged), "row_max_exp") &&
+         hip_ok(launch_row_max_exp(vb, xb, h->stream, tagged), "row_max_exp") &&
+         hip_ok(launch_mantissa_loss(va, xa, L, h->d_mantissa_loss_counter_ptr, h->stream, xw.tag), "loss") &&
+         hip_ok(launch_mantissa_loss(vb, xb, L, h->d_mantissa_loss_counter_ptr, h->stream, xw.tag), "loss");
   }
   if (!ok) return 3;
+  if (h->exp_reuse.armed) {
+    h->exp_reuse.valid = true;
+    h->exp_reuse.a = a, h->exp_reuse.b = b, h->exp_reuse.lda = lda, h->exp_reuse.ldb = ldb;
+    h->exp_reuse.m = m, h->exp_reuse.n = n, h->exp_reuse.k = k;
+    h->exp_reuse.op_a = (int)op_A, h->exp_reuse.op_b = (int)op_B, h->exp_reuse.parts = parts;
+  }
   unsigned long long host[16];
   // blocking download, as src/split.cu:404-408
   if (!hip_ok(hipMemcpyAsync(host, h->d_mantissa_loss_counter_ptr, sizeof(host), hipMemcpyDeviceToHost, h->stream),
@@ -999,11 +1043,17 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
       std::lock_guard<std::recursive_mutex> lock(h->mtx);
       if (stream_is_capturing(h->stream)) return 3;
     }
+    // statistic and GEMM under one lock: the GEMM may take over the row maxima the statistic pass has just computed
+    std::lock_guard<std::recursive_mutex> lock(h->mtx);
+    h->exp_reuse.armed = true;
     const ozimmu_compute_mode_t auto_mode = ozimmu_hip_auto_mode_select(
         h, op_A, op_B, m, n, k, a, lda, b, ldb, element_kind, h->avg_mantissa_loss_threshold);
+    h->exp_reuse.armed = false;
     log_info(std::string("AUTO selected mode = ") + ozimmu_hip_get_compute_mode_name_str(auto_mode) +
              ", threshold average mantissa loss = " + std::to_string(h->avg_mantissa_loss_threshold));
-    return ozimmu_hip_gemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, auto_mode, element_kind);
+    const int err = ozimmu_hip_gemm(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, auto_mode, element_kind);
+    h->exp_reuse.valid = false;
+    return err;
   }
   if (mode == OZIMMU_SGEMM) // src/cublas.cu:169-186 (the reference's library entry throws NOT_IMPLEMENTED here)
     return ozimmu_hip_gemm_f32(h, op_A, op_B, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, element_kind);

@@ -30,6 +30,18 @@ struct ozimmu_hip_handle {
   size_t exp_words_bytes = 0;
   uint32_t exp_epoch = 0;
 
+  // fp64_int8_auto: the statistic pass computes the row maxima of exactly the operands the GEMM it selects will split;
+  // it leaves them (tagged with exp_epoch) in exp_words and describes them here, and the GEMM that follows under the same
+  // lock skips its own row-maximum pass when the description matches.  Cleared by every other use of exp_words.
+  struct ExpReuse {
+    bool valid = false;
+    bool armed = false; // only the statistic pass of an fp64_int8_auto GEMM call publishes (the operands cannot change
+                        // between it and the GEMM: both run under one lock inside one API call)
+    const void *a = nullptr, *b = nullptr;
+    size_t lda = 0, ldb = 0, m = 0, n = 0, k = 0;
+    int op_a = 0, op_b = 0, parts = 0;
+  } exp_reuse;
+
   // Once a call of this handle has been captured into a graph, the graph holds pointers into the workspace and the
   // exponent-word buffer of that moment: blocks that are outgrown later are kept until the handle is destroyed instead of
   // freed, so that a replay never touches released memory.

@@ -122,7 +122,7 @@ hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int
 
 // auto mode: counters[s-3] += sum over elements of max(0, req - s*L), s = 3..18
 hipError_t launch_mantissa_loss(const OperandView &v, const uint32_t *exps, int L,
-                                unsigned long long *counters, hipStream_t stream);
+                                unsigned long long *counters, hipStream_t stream, uint32_t tag = 0);
 
 // ---- convert.hip: the `sgemm` compute mode (src/cublas_helper.cu:20-66) ---------------------------------
 // column-major rows x cols scalars; complex matrices pass rows = 2 * complex rows and ld = 2 * complex ld

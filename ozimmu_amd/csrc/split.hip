@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void mantissa_loss_kernel(const double *__rest
                                                             size_t K, size_t sr, size_t sk,
                                                             const uint32_t *__restrict__ exps, int L,
                                                             unsigned long long *counters, size_t RB,
-                                                            size_t KB) {
+                                                            size_t KB, uint32_t tag) {
   __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
   __shared__ unsigned long long blk[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void mantissa_loss_kernel(const double *__rest
     double v[16];
     load_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
     const size_t rg = rb * 32 + (lane & 31);
-    const unsigned e = rg < rows ? exps[rg] : 0u;
+    const unsigned e = rg < rows ? tagged_exp(exps[rg], tag) : 0u;
     if (e != 0u && e != 0x7FFu) { // max_exp != 0 (src/split.cu:322); non-finite rows carry no statistic
 #pragma unroll
       for (int q = 0; q < 16; q++) {
@@ -709,16 +709,16 @@ __global__ __launch_bounds__(256) void mantissa_loss_kernel(const double *__rest
 }
 
 hipError_t launch_mantissa_loss(const OperandView &v, const uint32_t *exps, int L,
-                                unsigned long long *counters, hipStream_t stream) {
+                                unsigned long long *counters, hipStream_t stream, uint32_t tag) {
   const size_t RB = (v.rows + 31) / 32, KB = k_blocks(v.K);
   if (RB * KB == 0) return hipSuccess;
   const unsigned grid = (unsigned)((RB * KB + 3) / 4);
   if (v.stride_k < v.stride_r)
     hipLaunchKernelGGL(mantissa_loss_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, v.stride_k, exps, L, counters, RB, KB);
+                       v.stride_r, v.stride_k, exps, L, counters, RB, KB, tag);
   else
     hipLaunchKernelGGL(mantissa_loss_kernel<false>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K,
-                       v.stride_r, v.stride_k, exps, L, counters, RB, KB);
+                       v.stride_r, v.stride_k, exps, L, counters, RB, KB, tag);
   return hipGetLastError();
 }
 

@@ -430,3 +430,46 @@ def test_gemm_fuzz_bit_exact(oz, seed):
         got = c.download()
         assert np.array_equal(got.view(np.uint64), c_ref.view.view(np.uint64)), \
             (seed, case, op_a, op_b, m, n, k, S, alpha, beta)
+
+
+@pytest.mark.parametrize("kind", ["real", "complex"])
+def test_auto_mode_gemm_equals_the_selected_mode_bitwise(oz, kind):
+    """fp64_int8_auto runs the statistic pass and then the GEMM of the mode it selects; the GEMM takes over the row maxima
+    the statistic pass has just computed instead of computing them again -- the result must be the selected mode's, bit for
+    bit (and a later plain call on the same, meanwhile MODIFIED operands must not see them)"""
+    import torch
+    m_, h = oz
+    m, n, k = 150, 130, 96
+    rng = np.random.default_rng(2024)
+    cplx = kind == "complex"
+    ek = m_.complx if cplx else m_.real
+    dt = torch.complex128 if cplx else torch.float64
+    def rnd(r, c):
+        x = torch.from_numpy(rng.uniform(-1, 1, (c, r)) * np.exp2(rng.integers(-6, 6, (c, 1)).astype(np.float64)))
+        return (torch.complex(x, x.flip(0)) if cplx else x).to(dt).cuda().contiguous()
+    a, b = rnd(m, k), rnd(k, n)
+    m_.set_auto_mantissa_loss_threashold(h, 1.0)
+    sel = m_.auto_mode_select(h, "N", "N", m, n, k, a, m, b, k, ek, 1.0)  # mode id (gemm takes ids or names)
+    assert "fp64_int8_" in m_.get_compute_mode_name_str(sel)
+    c_auto = torch.zeros(n, m, dtype=dt, device="cuda")
+    c_sel = torch.zeros(n, m, dtype=dt, device="cuda")
+    assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c_auto, m, "fp64_int8_auto", ek) == 0
+    assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c_sel, m, sel, ek) == 0
+    _sync()
+    assert torch.equal(torch.view_as_real(c_auto).view(torch.int64) if cplx else c_auto.view(torch.int64),
+                       torch.view_as_real(c_sel).view(torch.int64) if cplx else c_sel.view(torch.int64))
+    # the operands change in place (rows get 2^20 times larger): a plain call right after an auto call must compute
+    # its own row maxima
+    assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c_auto, m, "fp64_int8_auto", ek) == 0
+    a.mul_(2.0 ** 20)
+    c1 = torch.zeros(n, m, dtype=dt, device="cuda")
+    c2 = torch.zeros(n, m, dtype=dt, device="cuda")
+    assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c1, m, sel, ek) == 0
+    h2 = m_.create()
+    try:
+        assert m_.gemm(h2, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c2, m, sel, ek) == 0
+        _sync()
+    finally:
+        m_.destroy(h2)
+    assert torch.equal(torch.view_as_real(c1).view(torch.int64) if cplx else c1.view(torch.int64),
+                       torch.view_as_real(c2).view(torch.int64) if cplx else c2.view(torch.int64))
