@@ -5,6 +5,8 @@ result against the oracle evaluated in the kernel's own summation grouping (OZ_O
 the reference's pair-by-pair grouping (OZ_ORDER_REFERENCE) the FP64 result may differ only by the
 rounding of the regrouped sum -- tolerance stated in each test.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -473,3 +475,36 @@ def test_auto_mode_gemm_equals_the_selected_mode_bitwise(oz, kind):
         m_.destroy(h2)
     assert torch.equal(torch.view_as_real(c1).view(torch.int64) if cplx else c1.view(torch.int64),
                        torch.view_as_real(c2).view(torch.int64) if cplx else c2.view(torch.int64))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OZIMMU_TEST_FUZZ_SEEDS", "2"))))
+def test_gemm_fuzz_forced_kernels_bit_exact(oz, monkeypatch, seed):
+    """second fuzz: mid-size shapes (several tiles of every kernel, mixed tile heights, ragged edges) with the slice-GEMM
+    kernel forced at random (default policy / wide / classic / K-split), real and complex, batches of 1..3: bit-exact
+    against the oracle.  OZIMMU_TEST_FUZZ_SEEDS=n runs a longer campaign."""
+    import torch
+    m_, h = oz
+    rng = np.random.default_rng(77000 + seed)
+    for case in range(8):
+        m, n = int(rng.integers(1, 620)), int(rng.integers(1, 620))
+        k = int(rng.choice([33, 64, 96, 130, 257, 400]))
+        S = int(rng.choice([3, 4, 6, 8, 9, 10, 12, 13, 14, 16, 18]))
+        kernel = rng.choice(["", "wide", "classic", "k2"])
+        if kernel:
+            monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", str(kernel))
+        else:
+            monkeypatch.delenv("OZIMMU_HIP_GEMM_KERNEL", raising=False)
+        op_a, op_b = rng.choice(OPS), rng.choice(OPS)
+        alpha = float(rng.choice([1.0, -0.5, 2.75]))
+        beta = float(rng.choice([0.0, 1.0, -0.25]))
+        a = operand(op_a, m, k, rng, fill=exp_rand(2.0), pad=int(rng.integers(0, 3)))
+        b = operand(op_b, k, n, rng, fill=uniform_pm1, pad=int(rng.integers(0, 3)))
+        c = ColMajor(m, n, ld=m + int(rng.integers(0, 3)), fill=uniform_pm1, rng=rng)
+        c_ref = ColMajor(m, n, ld=c.ld)
+        c_ref.buf[...] = c.buf
+        assert m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, f"fp64_int8_{S}") == 0
+        _sync()
+        assert O.gemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+        got = c.download()
+        assert np.array_equal(got.view(np.uint64), c_ref.view.view(np.uint64)), \
+            (seed, case, kernel, op_a, op_b, m, n, k, S, alpha, beta)
