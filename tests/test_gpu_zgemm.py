@@ -150,3 +150,36 @@ def test_pytorch_complex128_matmul_is_intercepted():
         out[mode] = (float([l for l in p.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()[1]), p.stdout)
     assert out["fp64_int8_3"][0] > 1e-7 and out["fp64_int8_10"][0] < 1e-13, (out["fp64_int8_3"][0], out["fp64_int8_10"][0])
     assert "[CULiP Result][Zfp64_int8_10-" in out["fp64_int8_10"][1]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OZIMMU_TEST_FUZZ_SEEDS", "2"))))
+def test_zgemm_fuzz_forced_kernels_bit_exact(oz, monkeypatch, seed):
+    """complex fuzz: random shapes / ops / slice counts / complex alpha and beta with the slice-GEMM kernel forced at random
+    (the four real products run fused in one launch, one by one on the wide or the classic kernel, in one or two diagonal
+    passes): bit-exact against the oracle's ZGEMM.  OZIMMU_TEST_FUZZ_SEEDS=n runs a longer campaign."""
+    m_, h = oz
+    rng = np.random.default_rng(88000 + seed)
+    for case in range(6):
+        m, n = int(rng.integers(1, 420)), int(rng.integers(1, 420))
+        k = int(rng.choice([1, 33, 64, 130, 257]))
+        S = int(rng.choice([3, 6, 8, 9, 11, 13, 15, 18]))
+        kernel = rng.choice(["", "wide", "classic", "k2"])
+        if kernel:
+            monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", str(kernel))
+        else:
+            monkeypatch.delenv("OZIMMU_HIP_GEMM_KERNEL", raising=False)
+        op_a, op_b = rng.choice(["N", "T"]), rng.choice(["N", "T"])
+        a = zoperand(op_a, m, k, rng, "wide", pad=int(rng.integers(0, 3)))
+        b = zoperand(op_b, k, n, rng, "pm1", pad=int(rng.integers(0, 3)))
+        pad = int(rng.integers(0, 3))
+        c = zoperand("N", m, n, rng, pad=pad)
+        c_ref = ColMajor(m, n, ld=m + pad, dtype=np.complex128)
+        c_ref.buf[...] = c.buf
+        alpha = complex(rng.choice([1.0, -0.5, 1.25 - 0.5j]))
+        beta = complex(rng.choice([0.0, 1.0, -0.75 + 2.0j]))
+        assert m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, f"fp64_int8_{S}",
+                       m_.complx) == 0
+        _sync()
+        assert O.zgemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+        got = c.download()
+        assert np.array_equal(zbits(got), zbits(c_ref.view)), (seed, case, kernel, op_a, op_b, m, n, k, S, alpha, beta)
