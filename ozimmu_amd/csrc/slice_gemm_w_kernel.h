@@ -115,6 +115,7 @@ constexpr int VARW_NO_GLOBAL = 2;  // ablation: no staging (LDS holds garbage)
 constexpr int VARW_MFMA_ONLY = 4;  // ablation: no LDS reads either
 constexpr int VARW_NO_EPILOGUE = 128; // measurement: accumulators are only kept alive, nothing is converted or stored
 constexpr int VARW_B1 = 1024;      // ONE wave-private B buffer instead of two (see w_tile): passes with 14+ staged slices
+constexpr int VARW_HALF_BARRIERS = 2048; // measurement, WRONG RESULTS: the per-step barrier on every second k-step only
 constexpr int VARW_EPI_NOSTORE = 256; // measurement: epilogue without its stores
 constexpr int VARW_EPI_NOCHAIN = 512; // measurement: epilogue without its FP64 chains
 constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..107 of the first 32 workgroups -> p.acc
@@ -362,7 +363,10 @@ __device__ __forceinline__ void w_tile(const SliceGemmArgs &p, char *smem, const
         // returned.  NA == 3: it is refilled one k-step later; the reads (issued >= 4 MFMAs ago) are long gone by then.
         if constexpr (NA == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (TRACE) ts[2] = stamp();
-        __builtin_amdgcn_s_barrier(); // A of the next stage visible; nobody reads A of this stage from LDS any more
+        if constexpr ((VARW & VARW_HALF_BARRIERS) != 0) {
+          if (it & 1u) __builtin_amdgcn_s_barrier();
+        } else
+          __builtin_amdgcn_s_barrier(); // A of the next stage visible; nobody reads A of this stage from LDS any more
         asm volatile("" ::: "memory");
         if constexpr (TRACE) ts[3] = stamp();
         if constexpr (STAG > 0) // de-phase the 4 lockstep waves so that their copies do not queue in the TA

@@ -72,7 +72,7 @@ static float run_throttled(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e
 template <int S, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, int TAIL = 6, bool MIX = false, bool DYN = false>
 static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   constexpr int NA = (VARW & VARW_NA3) ? 3 : 2;
-  constexpr size_t lds = (size_t)(NA * WA + 2 * 4) * S * FRAG_BYTES;
+  constexpr size_t lds = (size_t)(NA * WA + ((VARW & VARW_B1) ? 1 : 2) * 4) * S * FRAG_BYTES;
   SliceGemmArgs a = a0;
   a.tiles_m = (a.M + 32 * WA - 1) / (32 * WA);
   a.tiles_m2 = 0;
@@ -184,6 +184,13 @@ int main(int argc, char **argv) {
       {"dma every 4, tail 8", run_w<S, W, 0, 0, -1, 4, 8, true, true>, false, {}},
       {"dma every 4, tail 5", run_w<S, W, 0, 0, -1, 4, 5, true, true>, false, {}},
       {"pd2, dma every 4, tail 6", run_w<S, W, VARW_NA3, 0, -1, 4, 6, true, true>, false, {}},
+      {"barrier on every second k-step only (wrong results: what halving the barriers could return)",
+       run_w<S, W, VARW_HALF_BARRIERS, 0, -1, 4, 6, true, true>, false, {}},
+      {"one B buffer", run_w<S, W, VARW_B1, 0, -1, 4, 6, true, true>, false, {}},
+      {"one B buffer, tail 4", run_w<S, W, VARW_B1, 0, -1, 4, 4, true, true>, false, {}},
+      {"one B buffer, tail 3", run_w<S, W, VARW_B1, 0, -1, 4, 3, true, true>, false, {}},
+      {"tail 3", run_w<S, W, 0, 0, -1, 4, 3, true, true>, false, {}},
+      {"tail 2", run_w<S, W, 0, 0, -1, 4, 2, true, true>, false, {}},
       {"mfma only", run_w<S, W, VARW_MFMA_ONLY, 0, -1, 4, 6, true, true>, false, {}},
   };
   for (int r = 0; r < rounds + 1; r++)
