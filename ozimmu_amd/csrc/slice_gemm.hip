@@ -28,7 +28,8 @@
 // Roofline: MFMA INT8 (dense 1024 MAC/clk/SIMD).  Algorithmic work per launch: P*2*M*N*K ops.
 //
 // Translation units: this file (dispatch on S, the complex beta scaling); slice_gemm_launch.h (kernel choice, tile plan,
-// launches) is instantiated for ranges of S by slice_gemm_s3_8.hip, _s9_11.hip, _s12_14.hip, _s15_18.hip.
+// launches) is instantiated for ranges of S by slice_gemm_s3_6.hip, _s7_10, _s11_13, _s14_15, _s16_16, _s17_17, _s18_18
+// (ranges balanced by compile time: a two-pass S costs three single-pass ones).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -60,25 +61,35 @@ hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, dou
   return hipGetLastError();
 }
 
-hipError_t launch_slice_gemm_s3_8(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_s9_11(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_s12_14(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_s15_18(int S, const SliceGemmArgs &a, hipStream_t stream);
-
-hipError_t launch_slice_gemm_fused_s3_8(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s9_11(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_s3_6(int S, const SliceGemmArgs &a, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s3_6(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_s7_10(int S, const SliceGemmArgs &a, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s7_10(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_s11_13(int S, const SliceGemmArgs &a, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s11_13(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_s14_15(int S, const SliceGemmArgs &a, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s14_15(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_s16_16(int S, const SliceGemmArgs &a, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s16_16(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_s17_17(int S, const SliceGemmArgs &a, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s17_17(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+hipError_t launch_slice_gemm_s18_18(int S, const SliceGemmArgs &a, hipStream_t stream);
+hipError_t launch_slice_gemm_fused_s18_18(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
 
 hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g, int count, hipStream_t stream) {
-  if (S >= 3 && S <= 8) return launch_slice_gemm_fused_s3_8(S, g, count, stream);
-  if (S >= 9 && S <= 11) return launch_slice_gemm_fused_s9_11(S, g, count, stream);
+  if (S >= 3 && S <= 6) return launch_slice_gemm_fused_s3_6(S, g, count, stream);
+  if (S >= 7 && S <= 10) return launch_slice_gemm_fused_s7_10(S, g, count, stream);
   return hipErrorNotSupported; // two diagonal passes per product, or no K-split kernel for this S
 }
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a, hipStream_t stream) {
-  if (S >= 3 && S <= 8) return launch_slice_gemm_s3_8(S, a, stream);
-  if (S >= 9 && S <= 11) return launch_slice_gemm_s9_11(S, a, stream);
-  if (S >= 12 && S <= 14) return launch_slice_gemm_s12_14(S, a, stream);
-  if (S >= 15 && S <= 18) return launch_slice_gemm_s15_18(S, a, stream);
+  if (S >= 3 && S <= 6) return launch_slice_gemm_s3_6(S, a, stream);
+  if (S >= 7 && S <= 10) return launch_slice_gemm_s7_10(S, a, stream);
+  if (S >= 11 && S <= 13) return launch_slice_gemm_s11_13(S, a, stream);
+  if (S >= 14 && S <= 15) return launch_slice_gemm_s14_15(S, a, stream);
+  if (S >= 16 && S <= 16) return launch_slice_gemm_s16_16(S, a, stream);
+  if (S >= 17 && S <= 17) return launch_slice_gemm_s17_17(S, a, stream);
+  if (S >= 18 && S <= 18) return launch_slice_gemm_s18_18(S, a, stream);
   return hipErrorInvalidValue;
 }
 

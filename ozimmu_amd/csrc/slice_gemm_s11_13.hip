@@ -1,0 +1,6 @@
+// slice-GEMM kernels and launch policy of fp64_int8_11 .. fp64_int8_13 (see slice_gemm_launch.h, slice_gemm.hip)
+#define OZ_S_LO 11
+#define OZ_S_HI 13
+#define OZ_PART launch_slice_gemm_s11_13
+#define OZ_PART_FUSED launch_slice_gemm_fused_s11_13
+#include "slice_gemm_launch.h"

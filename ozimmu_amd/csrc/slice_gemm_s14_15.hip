@@ -1,0 +1,6 @@
+// slice-GEMM kernels and launch policy of fp64_int8_14 .. fp64_int8_15 (see slice_gemm_launch.h, slice_gemm.hip)
+#define OZ_S_LO 14
+#define OZ_S_HI 15
+#define OZ_PART launch_slice_gemm_s14_15
+#define OZ_PART_FUSED launch_slice_gemm_fused_s14_15
+#include "slice_gemm_launch.h"

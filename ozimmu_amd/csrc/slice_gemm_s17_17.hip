@@ -1,0 +1,6 @@
+// slice-GEMM kernels and launch policy of fp64_int8_17 .. fp64_int8_17 (see slice_gemm_launch.h, slice_gemm.hip)
+#define OZ_S_LO 17
+#define OZ_S_HI 17
+#define OZ_PART launch_slice_gemm_s17_17
+#define OZ_PART_FUSED launch_slice_gemm_fused_s17_17
+#include "slice_gemm_launch.h"
