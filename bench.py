@@ -331,6 +331,32 @@ def main():
                 extra["fp64_int8_auto_thr1.5_tflops"] = tflops_of("fp64_int8_auto")   # includes the statistic pass
                 extra["fp64_int8_auto_relative_residual"] = sampled_relative_residual(
                     opa, opb, M, N, K, a_h, b_h, C2.cpu().numpy().T, ns=2048)
+            if args.mode == "fp64_int8_9" and opa == "N" and opb == "N":
+                # smaller squares of the same product (what the default 1024 intercept threshold lets through), next to
+                # native DGEMM: whole calls, inputs = leading blocks of the benchmark's operands re-packed densely
+                sizes = {}
+                for n_ in (1024, 2048, 4096):
+                    if n_ >= min(M, N, K):
+                        continue
+                    a_s = A[:n_, :n_].contiguous()
+                    b_s = B[:n_, :n_].contiguous()
+                    c_s = torch.zeros(n_, n_, dtype=torch.float64, device=A.device)
+                    reps_ = max(5, min(200, int(2e11 / n_ ** 3)))
+                    row = {}
+                    for name_, call_ in (("fp64_int8_9", lambda: oz.gemm(h, "N", "N", n_, n_, n_, 1.0, a_s, n_, b_s, n_, 0.0,
+                                                                        c_s, n_, "fp64_int8_9")),
+                                         ("rocblas_dgemm", lambda: oz.native_dgemm(h, "N", "N", n_, n_, n_, 1.0, a_s, n_, b_s,
+                                                                                   n_, 0.0, c_s, n_))):
+                        for _ in range(3):
+                            call_()
+                        torch.cuda.synchronize()
+                        t3 = time.perf_counter()
+                        for _ in range(reps_):
+                            call_()
+                        torch.cuda.synchronize()
+                        row[name_] = round(2.0 * n_ ** 3 * reps_ / (time.perf_counter() - t3) / 1e12, 2)
+                    sizes[str(n_)] = row
+                extra["square_sizes_tflops"] = sizes
             clk = clocks_under_load(1.5, step, torch.cuda.synchronize)
             if clk:
                 extra["clock_under_load"] = clk
