@@ -16,7 +16,7 @@
 // before its first MFMA (16*ND + 8*SL <= 224 registers of the 256 a wave has at two waves per SIMD), so the buffer of
 // step t is free for the copy of step t+2 one barrier later, and every copy has a full step to land.
 #pragma once
-#include "slice_gemm_kernel.h"
+#include "slice_gemm_w_kernel.h" // glds16: the LDS-DMA copy as inline asm
 
 namespace ozhip {
 
@@ -70,13 +70,23 @@ __device__ __forceinline__ void k2_tile(const SliceGemmArgs &p, char *smem) {
                                   : p.b_planes + (size_t)(2 * tn + (wave - 2)) * p.KB * (size_t)(S * FRAG_BYTES)) +
                         (size_t)kbeg * (S * FRAG_BYTES);
   const uint32_t lane_off = (uint32_t)lane * 16u;
+  // Copies as inline asm (glds16, slice_gemm_w_kernel.h): the compiler counts the LDS-DMA builtin on lgkmcnt as well and
+  // then waits for ALL fragment reads (lgkmcnt(0)) before a step's first MFMA; with the copies invisible to it the
+  // fragment waits are counted and the MFMAs start when the first fragments arrive.  The copies are ordered by the
+  // explicit vmcnt(0) in front of every barrier below.
+  const uint32_t lds_wave = (uint32_t)(size_t)((OZ_AS3 char *)sg) + (uint32_t)wave * (SL * FRAG_BYTES);
   auto stage = [&](uint32_t step) {
-    char *l = sg + (step & 1u) * STAGE + wave * (SL * FRAG_BYTES);
-    const int8_t *gu = src_u + (size_t)step * (S * FRAG_BYTES) + lane_off;
-#pragma unroll
-    for (int s = 0; s < SL; s++)
-      __builtin_amdgcn_global_load_lds((const OZ_AS1 void *)(gu + s * FRAG_BYTES), (OZ_AS3 void *)(l + s * FRAG_BYTES),
-                                       16, 0, OZ_GLDS_AUX);
+    const int8_t *sb = uniform_ptr(src_u + (size_t)step * (S * FRAG_BYTES));
+    const uint32_t lds_buf = lds_wave + (step & 1u) * STAGE;
+    static_for<SL>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int G = 4, g0 = s / G * G; // the immediate offset (0 .. 3072) advances the LDS address too
+      glds16<(s % G) * FRAG_BYTES>(sb + g0 * FRAG_BYTES, lane_off, lds_buf, (uint32_t)(g0 * FRAG_BYTES));
+    });
+  };
+  auto sync = [&]() { // own copies landed, then everybody's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
 
   v16i acc[ND];
@@ -126,7 +136,7 @@ __device__ __forceinline__ void k2_tile(const SliceGemmArgs &p, char *smem) {
   if (nkg) stage(0);
   if (grp == 0) {
     for (uint32_t t = 0; t < nit; t++) {
-      __syncthreads(); // copies of step t landed (vmcnt(0) precedes the barrier); step t-1 is done with the other buffer
+      sync(); // copies of step t landed (vmcnt(0) precedes the barrier); step t-1 is done with the other buffer
       if (t + 1 < nit) stage(t + 1);
       read_fragments(t);
       __builtin_amdgcn_sched_barrier(0);
@@ -135,7 +145,7 @@ __device__ __forceinline__ void k2_tile(const SliceGemmArgs &p, char *smem) {
     }
   } else {
     if (nkg) {
-      __syncthreads();
+      sync();
       if (1 < nkg) stage(1);
       read_fragments(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -143,7 +153,7 @@ __device__ __forceinline__ void k2_tile(const SliceGemmArgs &p, char *smem) {
       __builtin_amdgcn_sched_barrier(0);
     }
     for (uint32_t t = 1; t < nkg; t++) {
-      __syncthreads(); // step t landed; the fragments of step t-1 are in registers: its buffer takes step t+1
+      sync(); // step t landed; the fragments of step t-1 are in registers: its buffer takes step t+1
       if (t + 1 < nkg) stage(t + 1);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(IC{}, IN{});
@@ -154,7 +164,7 @@ __device__ __forceinline__ void k2_tile(const SliceGemmArgs &p, char *smem) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (nkg) mfmas(IC{}, IN{});
-    if (nkg < nit) __syncthreads(); // odd number of k-blocks: group 0 ran one more round
+    if (nkg < nit) sync(); // odd number of k-blocks: group 0 ran one more round
   }
 
   // ---- group 1 -> group 0: INT32 accumulators through LDS (the staging buffers are dead) -------------------------
