@@ -46,7 +46,11 @@ extern "C" {
 
 typedef struct ozimmu_hip_handle *ozimmu_hip_handle_t; /* include/ozimmu/ozimmu.hpp:9-11 */
 
-typedef enum { OZIMMU_OP_N = 0, OZIMMU_OP_T = 1 } ozimmu_operation_t; /* ozimmu.hpp:12 */
+/* ozimmu.hpp:12 has op_n, op_t only: the reference's cuBLAS hook maps CUBLAS_OP_C to op_t (src/cublas.cu:50-56), so its
+ * ZGEMM with a conjugate-transposed operand computes A^T B instead of A^H B.  OZIMMU_OP_C is the conjugate transpose, computed
+ * correctly (complex element kind: the imaginary part of that operand enters with the opposite sign; real: the same as
+ * OZIMMU_OP_T). */
+typedef enum { OZIMMU_OP_N = 0, OZIMMU_OP_T = 1, OZIMMU_OP_C = 2 } ozimmu_operation_t;
 
 /* include/ozimmu/ozimmu.hpp:14-37 — same order, so the integer values match the reference enum */
 typedef enum {

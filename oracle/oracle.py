@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboz_oracle.so")
 
-OP_N, OP_T = 0, 1
+OP_N, OP_T, OP_C = 0, 1, 2   # OP_C: conjugate transpose (complex entry points; the real ones treat it as OP_T)
 ORDER_REFERENCE, ORDER_DIAGONAL = 0, 1
 QUIRK_REF_SUBNORMAL = 1
 
@@ -80,7 +80,7 @@ def _p(a):
 
 def op_code(op):
     if isinstance(op, str):
-        return OP_N if op.upper() == "N" else OP_T
+        return {"N": OP_N, "T": OP_T, "C": OP_C}[op.upper()]
     return int(op)
 
 

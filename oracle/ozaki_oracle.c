@@ -311,6 +311,18 @@ int oz_oracle_zgemm(int op_a, int op_b, size_t m, size_t n, size_t k, const doub
   if (bad_shape(op_a, m, k, lda) || bad_shape(op_b, k, n, ldb) || bad_shape(OZ_OP_N, m, n, ldc)) return 1;
   if (S < 3 || S > 18) return 1;
   if (m == 0 || n == 0) return 0;
+  /* OZ_OP_C (ozaki_oracle.h): a copy of the operand with Im negated, then the op_t path */
+  double *a_conj = NULL, *b_conj = NULL;
+  if (op_a == OZ_OP_C) {
+    a_conj = (double *)malloc(sizeof(double) * 2 * lda * (m ? m : 1));
+    for (size_t i = 0; i < lda * m; i++) a_conj[2 * i] = a[2 * i], a_conj[2 * i + 1] = -a[2 * i + 1];
+    a = a_conj, op_a = OZ_OP_T;
+  }
+  if (op_b == OZ_OP_C) {
+    b_conj = (double *)malloc(sizeof(double) * 2 * ldb * (k ? k : 1));
+    for (size_t i = 0; i < ldb * k; i++) b_conj[2 * i] = b[2 * i], b_conj[2 * i + 1] = -b[2 * i + 1];
+    b = b_conj, op_b = OZ_OP_T;
+  }
   const int L = (int)oz_oracle_bits_per_int8((uint32_t)k); /* :425 */
   const size_t ldo = oz_oracle_pad4(k);
   const size_t pl = ldo ? ldo : 1;
@@ -372,6 +384,7 @@ int oz_oracle_zgemm(int op_a, int op_b, size_t m, size_t n, size_t k, const doub
   }
   for (int q = 0; q < 2; q++) free(ap[q]), free(bp[q]), free(ea[q]), free(eb[q]);
   free(acc);
+  free(a_conj), free(b_conj);
   return rc;
 }
 
@@ -555,8 +568,10 @@ double oz_oracle_relative_residual_sampled_z(int op_a, int op_b, size_t m, size_
       for (size_t kk = 0; kk < k; kk++) {
         const double *pa = a + 2 * (op_a == OZ_OP_N ? kk * lda + i : i * lda + kk);
         const double *pb = b + 2 * (op_b == OZ_OP_N ? j * ldb + kk : kk * ldb + j);
-        re += (long double)pa[0] * pb[0] - (long double)pa[1] * pb[1];
-        im += (long double)pa[0] * pb[1] + (long double)pa[1] * pb[0];
+        const long double ai = op_a == OZ_OP_C ? -(long double)pa[1] : (long double)pa[1];
+        const long double bi = op_b == OZ_OP_C ? -(long double)pb[1] : (long double)pb[1];
+        re += (long double)pa[0] * pb[0] - ai * bi;
+        im += (long double)pa[0] * bi + ai * pb[0];
       }
       const long double dr = (long double)c[2 * (j * ldc + i)] - re, di = (long double)c[2 * (j * ldc + i) + 1] - im;
       lnum += dr * dr + di * di;

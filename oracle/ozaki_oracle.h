@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-enum { OZ_OP_N = 0, OZ_OP_T = 1 };
+/* OZ_OP_C (complex entry points only): conjugate transpose.  The reference maps CUBLAS_OP_C to op_t and never conjugates
+ * (src/cublas.cu:50-56: A^H B comes out as A^T B); the oracle states what the BLAS call means: the operand with its
+ * imaginary part negated, then the reference's op_t path.  In the real entry points OZ_OP_C is OZ_OP_T. */
+enum { OZ_OP_N = 0, OZ_OP_T = 1, OZ_OP_C = 2 };
 
 /* accumulation order of the FP64 recombination */
 enum {

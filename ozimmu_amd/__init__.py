@@ -12,12 +12,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# OZIMMU_HIP_LIBRARY: another flavour of the library for these bindings (e.g. ozimmu_amd/libozimmu_hip_release.so, the
-# hook-free build of `python -m ozimmu_amd.build --release`)
+# libozimmu_hip.so is what ships: no test hook compiled in.  OZIMMU_HIP_LIBRARY points these bindings at another build.
 LIB_PATH = os.environ.get("OZIMMU_HIP_LIBRARY") or os.path.join(_HERE, "libozimmu_hip.so")
+# the same sources with -DOZIMMU_HIP_TEST_HOOKS (INT32 diagonal-sum dump, launch-failure injection, epoch jump): only the tests
+# that drive those hooks load it, through test_flavour() below
+TEST_LIB_PATH = os.path.join(_HERE, "libozimmu_hip_test.so")
 
-# include/ozimmu/ozimmu.hpp:12
-op_n, op_t = 0, 1
+# include/ozimmu/ozimmu.hpp:12 (op_c: conjugate transpose, include/ozimmu_hip.h - the reference has no such value)
+op_n, op_t, op_c = 0, 1, 2
 # include/ozimmu/ozimmu.hpp:14-37
 (sgemm, dgemm, fp64_int8_3, fp64_int8_4, fp64_int8_5, fp64_int8_6, fp64_int8_7, fp64_int8_8,
  fp64_int8_9, fp64_int8_10, fp64_int8_11, fp64_int8_12, fp64_int8_13, fp64_int8_14, fp64_int8_15,
@@ -114,7 +116,7 @@ def _ptr(x):
 
 def _op(op):
     if isinstance(op, str):
-        return op_n if op.upper() == "N" else op_t
+        return {"N": op_n, "T": op_t, "C": op_c}[op.upper()]
     return int(op)
 
 
@@ -305,3 +307,21 @@ def version():
 
 
 PRELOAD_ENV = {"LD_PRELOAD": LIB_PATH}
+
+_test_flavour = None
+
+
+def test_flavour():
+    """A second, independent copy of these bindings over libozimmu_hip_test.so (own library image, own handles): the module
+    source executed again under another name with LIB_PATH = TEST_LIB_PATH.  For the tests that need a hook; everything
+    else - including every parity test that only calls the product API - stays on the library that ships."""
+    global _test_flavour
+    if _test_flavour is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ozimmu_amd_test_flavour", os.path.abspath(__file__))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.LIB_PATH = TEST_LIB_PATH
+        mod.PRELOAD_ENV = {"LD_PRELOAD": TEST_LIB_PATH}
+        _test_flavour = mod
+    return _test_flavour

@@ -1,6 +1,12 @@
-"""Builds ozimmu_amd/libozimmu_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Builds the library in-tree with hipcc for gfx950 (cross-compiles without a GPU), in two flavours from the same sources:
 
-    python -m ozimmu_amd.build [--force] [--release]
+    ozimmu_amd/libozimmu_hip.so        what ships: no test hook anywhere (objects in build/).  The bindings, bench.py, smoke(),
+                                       the LD_PRELOAD tests and every parity test that needs no hook load THIS file.
+    ozimmu_amd/libozimmu_hip_test.so   -DOZIMMU_HIP_TEST_HOOKS (objects in build_test/): the INT32 diagonal-sum dump of the
+                                       kernels' epilogues, launch-failure injection, the epoch jump - loaded only by the
+                                       tests that drive those hooks (tests/conftest.py: `ozh`).
+
+    python -m ozimmu_amd.build [--force] [--no-test-flavour | --test-flavour-only]
 
 The .so is git-ignored but travels with the tree (gpurun snapshot); nothing is installed or JIT-cached.
 """
@@ -13,7 +19,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libozimmu_hip.so")
-LIB_RELEASE = os.path.join(HERE, "libozimmu_hip_release.so")
+LIB_TEST = os.path.join(HERE, "libozimmu_hip_test.so")
 GEMM_PARTS = ["slice_gemm_s3_6.hip", "slice_gemm_s7_10.hip", "slice_gemm_s11_13.hip", "slice_gemm_s14_15.hip", "slice_gemm_s16_16.hip", "slice_gemm_s17_17.hip", "slice_gemm_s18_18.hip"]
 SOURCES = GEMM_PARTS + ["slice_gemm.hip", "topology.hip", "split.hip", "convert.hip", "api.cpp", "config.cpp", "interpose.cpp"]
 HEADERS = ["kernels.h", "config.h", "topology.h", "tile_plan.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", "slice_gemm_x_tile.h", "slice_gemm_y_tile.h", "slice_gemm_k2_kernel.h",
@@ -59,30 +65,37 @@ def _compile(hipcc, common, s, verbose, bdir="build"):
     return obj
 
 
-def build(force=False, verbose=False, release=False):
-    """default: libozimmu_hip.so with -DOZIMMU_HIP_TEST_HOOKS (the diagonal-sum dump of the kernels, launch-failure
-    injection, the epoch jump: what tests/ drive); release=True: libozimmu_hip_release.so, the same sources without any
-    hook (objects in build_release/) - the flavour to deploy behind LD_PRELOAD"""
-    hipcc = _hipcc()
-    bdir = "build_release" if release else "build"
-    lib = LIB_RELEASE if release else LIB
-    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+def _flavour(hooks):
+    bdir = "build_test" if hooks else "build"
     common = ["-O3", "-std=c++17", "-fPIC", "-I" + CSRC, "-D__HIP_PLATFORM_AMD__", "-Wall",
-              "-Wno-unused-function", "-Wno-unused-value"] + ([] if release else ["-DOZIMMU_HIP_TEST_HOOKS"])
-    os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
+              "-Wno-unused-function", "-Wno-unused-value"] + (["-DOZIMMU_HIP_TEST_HOOKS"] if hooks else [])
     objs = [os.path.join(HERE, bdir, s.rsplit(".", 1)[0] + ".o") for s in SOURCES]
-    todo = [s for s, obj in zip(SOURCES, objs) if force or _stale(obj, [os.path.join(CSRC, s)] + deps)]
-    # the translation units are independent: compile them side by side (the slice-GEMM parts take minutes each)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
-        for f in [pool.submit(_compile, hipcc, common, s, verbose, bdir) for s in todo]:
+    return bdir, common, objs, (LIB_TEST if hooks else LIB)
+
+
+def build(force=False, verbose=False, test_flavour=True, product=True):
+    """compiles the stale translation units of both flavours side by side (the slice-GEMM parts take minutes each), links
+    libozimmu_hip.so (the product) and libozimmu_hip_test.so (with the test hooks); returns the product's path"""
+    hipcc = _hipcc()
+    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    flavours = [_flavour(h) for h in ([False] if product else []) + ([True] if test_flavour else [])]
+    jobs = []
+    for bdir, common, objs, _ in flavours:
+        os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
+        jobs += [(common, s, bdir) for s, obj in zip(SOURCES, objs) if force or _stale(obj, [os.path.join(CSRC, s)] + deps)]
+    jobs.sort(key=lambda j: j[1] not in GEMM_PARTS)  # the long ones first
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+        for f in [pool.submit(_compile, hipcc, common, s, verbose, bdir) for common, s, bdir in jobs]:
             f.result()
-    if force or _stale(lib, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + ["-ldl", "-lpthread"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    return lib
+    for bdir, common, objs, lib in flavours:
+        if force or _stale(lib, objs):
+            cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + ["-ldl", "-lpthread"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, release="--release" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, test_flavour="--no-test-flavour" not in sys.argv,
+                product="--test-flavour-only" not in sys.argv))

@@ -61,14 +61,19 @@ bool is_int8_mode(ozimmu_compute_mode_t mode) { return num_split_of_mode(mode) !
 
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-// largest K (multiple of 32) whose per-diagonal INT32 sums cannot overflow: at most S products of
-// magnitude <= (2^L-1)^2 per k.  (The reference bounds a single pair: k*2^(2L) <= 2^31, src/split.cu:520-536.)
+// largest K whose per-diagonal INT32 sums cannot overflow: at most S products of magnitude <= (2^L-1)^2 per k.  (The
+// reference bounds a single pair: k*2^(2L) <= 2^31, src/split.cu:520-536.)  A multiple of 64 (of 32 below 64): a pass then
+// holds an EVEN number of k-blocks (the k64 tile function walks two per step), and every k <= max_k_per_pass has
+// k_blocks(k) <= kb_per_pass - the planes pad odd block counts beyond 32 up to even (layout.h) - so "single pass" means
+// the same thing to the workspace layout (needs_acc) and to the K loops below.
 static size_t max_k_per_pass(int S, int L) {
   if (L <= 0 || S <= 0) return 32; // no safe slice width (k == 0 or k > 2^30): callers route such calls elsewhere
   const unsigned long long q = (1ull << L) - 1ull;
   const unsigned long long kc = 2147483647ull / ((unsigned long long)S * q * q);
-  return (size_t)std::max<unsigned long long>(32ull, kc / 32ull * 32ull);
+  return (size_t)(kc >= 64ull ? kc / 64ull * 64ull : 32ull);
 }
+// k-blocks one launch may cover (even, or 1)
+static uint32_t kb_per_pass(int S, int L) { return (uint32_t)(max_k_per_pass(S, L) / FRAG_K); }
 
 struct Workspace {
   double *ea, *eb;
@@ -110,7 +115,7 @@ static int bits_for_k(size_t k) {
 static bool needs_acc(size_t k, int S) {
   const int L = bits_for_k(k);
   if (L == 0) return false;
-  return S > SINGLE_PASS_MAX_S || k > max_k_per_pass(S, L);
+  return S > SINGLE_PASS_MAX_S || k_blocks(k) > (size_t)kb_per_pass(S, L);
 }
 
 static OperandView view_A(ozimmu_operation_t op, size_t m, size_t k, const double *a, size_t lda) {
@@ -482,11 +487,11 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   g.dump = dump;
   g.dump_only = dump ? 1 : 0;
   // (an even number of k-blocks per pass: the k64 tile function walks two per step)
-  const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K) >= 2u ? ((uint32_t)(kc / FRAG_K) & ~1u) : 1u;
+  const uint32_t kbp = kb_per_pass(S, L);
   int launches = 0;
-  for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
+  for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kbp) {
     g.kb0 = kb0;
-    g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
+    g.kb1 = std::min(g.KB, kb0 + kbp);
     g.acc_in = kb0 != 0;
     g.final = g.kb1 == g.KB;
     g.qslot = 2u * (uint32_t)launches; // per-launch claim counters of the wide kernel (two per K chunk: S > 12)
@@ -546,13 +551,16 @@ static WorkspaceZ carve_z(void *base, size_t m, size_t n, size_t k, int S, bool 
 // scaled by beta first, then four real Ozaki products (Im,Im), (Re,Re), (Im,Re), (Re,Im) are added with the
 // factors -alpha, alpha, i*alpha, i*alpha -- in that order (:479-518).  Each product runs the same fused kernel
 // as the real path; its epilogue adds the scaled product into the complex C.
+// OZIMMU_OP_C (conjugate transpose; the reference runs it as a plain transpose, src/cublas.cu:50-56, which is the wrong
+// product): conj(X) = Re(X) - i Im(X), and the slice cut is odd in its argument (the sign is applied after the truncation,
+// src/split.cu:159, :176-181) with row maxima that ignore the sign, so the slices of -Im(X) are the negated slices of Im(X):
+// the operand is split exactly like op T and every product that contains its imaginary part changes the sign of its factor.
 static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,
                              size_t n, size_t k, const double *alpha, const double *a, size_t lda, const double *b,
                              size_t ldb, const double *beta, double *c, size_t ldc, int S,
                              const BatchSpec &bs = BatchSpec()) {
   const int L = bits_for_k(k);
   if (L == 0) return 3;
-  const size_t kc = max_k_per_pass(S, L);
   const bool acc_needed = needs_acc(k, S);
   WorkspaceZ sz = carve_z(nullptr, m, n, k, S, acc_needed);
   const size_t slot = sz.total;
@@ -639,6 +647,10 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
       g.alpha = -alpha[1];
       g.alpha_im = alpha[0];
     }
+    if ((pq[0] == 1 && op_A == OZIMMU_OP_C) != (pq[1] == 1 && op_B == OZIMMU_OP_C)) { // one conjugated imaginary part
+      g.alpha = -g.alpha;
+      g.alpha_im = -g.alpha_im;
+    }
     g.c = c;
     g.ldc = ldc;
     g.acc = w.acc;
@@ -649,9 +661,9 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     g.c_stride = bs.stride_c;
   }
   // (an even number of k-blocks per pass: the k64 tile function walks two per step)
-  const uint32_t kb_per_pass = (uint32_t)(kc / FRAG_K) >= 2u ? ((uint32_t)(kc / FRAG_K) & ~1u) : 1u;
+  const uint32_t kbp = kb_per_pass(S, L);
   bool fused = false;
-  if (prod[0].KB <= kb_per_pass && !config().test_fail_launch) {
+  if (prod[0].KB <= kbp && !config().test_fail_launch) {
     // one K chunk: the four products may run as ONE launch when the K-split kernel applies (small problems: three launch
     // and drain rounds less); same order of updates per element of C.  (The fault-injection test addresses launches by
     // number and keeps the one-by-one form.)
@@ -674,9 +686,9 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   }
   for (int q = 0; q < 4 && !fused; q++) {
     SliceGemmArgs &g = prod[q];
-    for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kb_per_pass) {
+    for (uint32_t kb0 = 0; kb0 < g.KB; kb0 += kbp) {
       g.kb0 = kb0;
-      g.kb1 = std::min(g.KB, kb0 + kb_per_pass);
+      g.kb1 = std::min(g.KB, kb0 + kbp);
       g.acc_in = kb0 != 0;
       g.final = g.kb1 == g.KB;
       g.qslot = 2u * (uint32_t)launches;
@@ -885,7 +897,8 @@ size_t ozimmu_hip_working_memory_size(ozimmu_operation_t, ozimmu_operation_t, si
 }
 
 static rocblas_operation to_rocblas_op(ozimmu_operation_t op) {
-  return op == OZIMMU_OP_N ? rocblas_operation_none : rocblas_operation_transpose;
+  return op == OZIMMU_OP_N ? rocblas_operation_none
+                           : op == OZIMMU_OP_C ? rocblas_operation_conjugate_transpose : rocblas_operation_transpose;
 }
 
 int ozimmu_hip_native_dgemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_operation_t op_B, size_t m,

@@ -23,7 +23,8 @@
 //     instead of the reference's sequential per-matrix loop (:380-406);
 //   * a failure BEFORE C was touched falls back to the vendor routine; a failure after C was modified is reported as an
 //     error status (the reference overwrites every status with SUCCESS, :215-219) -- never a silent double update;
-//   * device pointer mode, out-of-place gemm_ex (C != D) and conjugate-transposed complex operands are passed through;
+//   * device pointer mode and out-of-place gemm_ex (C != D) are passed through; conjugate-transposed complex operands are
+//     computed as such (OZIMMU_OP_C), not as plain transposes (:50-56);
 //   * a thread-local guard keeps the shim from re-intercepting calls made underneath itself
 //     (hipBLAS -> rocBLAS, and this library's own native-DGEMM fallback);
 //   * the caller's stream travels WITH the call (ozimmu_hip_gemm_on_stream takes the handle's lock before it switches
@@ -207,10 +208,9 @@ struct RB { // rocBLAS
     *host_mode = pm == rocblas_pointer_mode_host;
     return true;
   }
-  static ozimmu_operation_t to_oz(operation op) { // src/cublas.cu:50-56: every non-N is T
-    return op == rocblas_operation_none ? OZIMMU_OP_N : OZIMMU_OP_T;
+  static ozimmu_operation_t to_oz(operation op) { // (src/cublas.cu:50-56 maps every non-N to T: wrong for complex data)
+    return op == rocblas_operation_none ? OZIMMU_OP_N : op == rocblas_operation_conjugate_transpose ? OZIMMU_OP_C : OZIMMU_OP_T;
   }
-  static bool conj(operation op) { return op == rocblas_operation_conjugate_transpose; }
 };
 struct HB { // hipBLAS: only reached when an application binds hipBLAS statically or resolves these first
   typedef hipblasStatus_t status;
@@ -229,18 +229,19 @@ struct HB { // hipBLAS: only reached when an application binds hipBLAS staticall
     *host_mode = pm == HIPBLAS_POINTER_MODE_HOST;
     return true;
   }
-  static ozimmu_operation_t to_oz(operation op) { return op == HIPBLAS_OP_N ? OZIMMU_OP_N : OZIMMU_OP_T; }
-  static bool conj(operation op) { return op == HIPBLAS_OP_C; }
+  static ozimmu_operation_t to_oz(operation op) {
+    return op == HIPBLAS_OP_N ? OZIMMU_OP_N : op == HIPBLAS_OP_C ? OZIMMU_OP_C : OZIMMU_OP_T;
+  }
 };
 
 // Common body of every interposed GEMM: try the Ozaki path when `eligible` (types / in-place checks of the caller),
-// else (or when it declines) forward to the vendor definition.  Complex operands with a conjugate-transpose are passed
-// through: the reference maps every non-N operation to a plain transpose (src/cublas.cu:50-56), wrong for complex data.
+// else (or when it declines) forward to the vendor definition.  Conjugate-transposed complex operands take the Ozaki path
+// as OZIMMU_OP_C (the reference maps every non-N operation to a plain transpose, src/cublas.cu:50-56: wrong for complex data).
 template <class V, class Forward>
 typename V::status entry(bool eligible, typename V::handle handle, typename V::operation ta, typename V::operation tb,
                          GemmCall g, bool have_fn, Forward forward) {
   ozimmu_compute_mode_t mode = OZIMMU_DGEMM;
-  if (t_depth == 0 && eligible && g.batch > 0 && !(g.cplx && (V::conj(ta) || V::conj(tb))) &&
+  if (t_depth == 0 && eligible && g.batch > 0 &&
       (mode = get_compute_mode()) != OZIMMU_DGEMM) { // the one per-call read of OZIMMU_COMPUTE_MODE (src/cublas.cu:18-48)
     hipStream_t stream = nullptr;
     bool host_mode = false;

@@ -205,7 +205,25 @@ struct K64Cfg {
   static constexpr bool ok = WA >= 2;
   static constexpr size_t LDS = lds(WA > 0 ? WA : 1, NB);
   static constexpr int DMAE = 8, TAIL = 12;
+  // VARW_BREG (slice_gemm_y_tile.h): the B fragments global -> VGPR into two named register sets of 2 * S fragments
+  // (v[112:255]: S <= 9), LDS holds the two A stages only.  64 x 128 tiles; where the LDS form has the same tile height it
+  // stages a third of the bytes into LDS and reads two thirds of the fragments from it.
+  static constexpr int BREG_WA = 2;
+  static constexpr bool breg_ok = S <= 9 && WA == BREG_WA && BREG_WA * S * 16 + 16 * S + 4 * 4 + 4 + 24 <= 512;
+  static constexpr size_t BREG_LDS = (size_t)(2 * BREG_WA) * (2 * S) * FRAG_BYTES;
 };
+// B global -> VGPR: the step has ONE form (every step prefetches; the last one wraps around), two steps per loop iteration:
+// passes with an even number of 64-k steps.  Measured at 8192^3, S = 9 (profiles/r4_ablate/): see DESIGN.md 4.2.
+template <int ND>
+static bool k64_breg(const SliceGemmArgs &a) {
+  if constexpr (!K64Cfg<ND>::breg_ok) {
+    return false;
+  } else {
+    if (((a.kb1 - a.kb0) & 3u) != 0) return false;
+    if (config().k64_breg >= 0) return config().k64_breg == 1;
+    return true;
+  }
+}
 // Measured against the 32x32x32 tile function on real slices of U[-1,1) data (profiles/r3_ablate/r3v_k64_tile_real_data_ab.txt):
 // 8192^3 S = 5 / 6 / 7 / 8 / 9 / 10: -13 / -10 / -7.5 / -10 / -7.5 / -9 % time (S = 9: 66.9 -> 72.3 TFLOP/s), 4096^3 S = 6 / 8 / 9:
 // -13 / -12 / -9 %, 2048^3 S = 9: -3 %.  The default wherever it exists; OZIMMU_HIP_K64_TILE=1 / 0 forces it on / off.
@@ -227,6 +245,10 @@ static hipError_t launch_wide_kernel(const SliceGemmArgs &a0, const WidePlan &pl
 template <int S, int ND>
 static hipError_t launch_wide_k64(const SliceGemmArgs &a, const WidePlan &pl, hipStream_t stream) {
   using C = K64Cfg<ND>;
+  if constexpr (C::breg_ok) {
+    if (k64_breg<ND>(a))
+      return launch_wide_kernel<S, ND, C::BREG_WA, VARW_K64 | VARW_BREG, C::DMAE, C::TAIL>(a, pl, C::BREG_LDS, stream);
+  }
   return launch_wide_kernel<S, ND, C::WA, VARW_K64 | (C::NB == 1 ? VARW_B1 : 0), C::DMAE, C::TAIL>(a, pl, C::LDS, stream);
 }
 
@@ -268,10 +290,15 @@ static hipError_t launch_wide_multi_impl(const SliceGemmArgs *g, int count, cons
   hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), lds, stream, m);
   return hipGetLastError();
 }
-template <int S>
+template <int S, bool BREG = false>
 static hipError_t launch_wide_multi_k64(const SliceGemmArgs *g, int count, const WidePlan &pl, hipStream_t stream) {
   using C = K64Cfg<S>;
-  auto kernel = slice_gemm_w_multi_kernel<S, 0, S, C::WA, VARW_K64 | (C::NB == 1 ? VARW_B1 : 0), 0, -1, C::DMAE, C::TAIL>;
+  if constexpr (C::breg_ok && !BREG) {
+    if (k64_breg<S>(g[0])) return launch_wide_multi_k64<S, true>(g, count, pl, stream);
+  }
+  constexpr int WAK = BREG ? C::BREG_WA : C::WA;
+  constexpr size_t LDSK = BREG ? C::BREG_LDS : C::LDS;
+  auto kernel = slice_gemm_w_multi_kernel<S, 0, S, WAK, VARW_K64 | (BREG ? VARW_BREG : (C::NB == 1 ? VARW_B1 : 0)), 0, -1, C::DMAE, C::TAIL>;
   SliceGemmMulti m{};
   m.count = count;
   uint32_t nb = 0;
@@ -281,8 +308,8 @@ static hipError_t launch_wide_multi_k64(const SliceGemmArgs *g, int count, const
     nb = wide_grid(m.g[i], pl);
   }
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = allow_dynamic_lds(kernel, C::LDS, attr_done)) return e;
-  hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), C::LDS, stream, m);
+  if (hipError_t e = allow_dynamic_lds(kernel, LDSK, attr_done)) return e;
+  hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), LDSK, stream, m);
   return hipGetLastError();
 }
 template <int S>

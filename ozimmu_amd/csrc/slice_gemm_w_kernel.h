@@ -64,6 +64,36 @@ __device__ __forceinline__ void glds16(const int8_t *sbase, uint32_t voff, uint3
                : "memory");
 }
 
+// VARW_BREG (slice_gemm_y_tile.h): the B fragments of the k64 tile live in HAND-ALLOCATED registers v[112:255] (two sets of
+// 2 * S fragments of 4 registers, S <= 9).  hipcc's allocator, handed 36 live 128-bit tuples next to 72 accumulator tuples,
+// splits live ranges between the two parities of the step and spills (1.4 KiB of scratch, hundreds of v_accvgpr copies inside
+// the k loop); named registers cost nothing.  Every asm statement of the k loop that reads or writes them lists the whole
+// range as clobbered, so the compiler keeps no value there across any of them; tests/test_isa_invariants.py checks that no
+// compiler-generated instruction of a BREG kernel touches the range at all.
+#define OZ_BREG_FIRST 112
+#define OZ_BREG_CLOBBERS \
+  "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", \
+  "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", \
+  "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", \
+  "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", \
+  "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", \
+  "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", \
+  "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", \
+  "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", \
+  "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", \
+  "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", \
+  "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+// fragment -> VGPR: lane l loads the 16 bytes at sbase + voff(l) + IMM into v[REG : REG + 3].  Inline asm for the same reason
+// as glds16: the compiler does not count it, the consumer waits with an explicit vmcnt.
+template <int REG, int IMM>
+__device__ __forceinline__ void gload16_named(const int8_t *sbase, uint32_t voff) {
+  static_assert(REG >= OZ_BREG_FIRST && REG + 3 <= 255 && (REG & 3) == 0, "inside the reserved range");
+  asm volatile("global_load_dwordx4 v[%c0:%c1], %2, %3 offset:%c4"
+               :
+               : "i"(REG), "i"(REG + 3), "v"(voff), "s"(sbase), "i"(IMM)
+               : "memory", OZ_BREG_CLOBBERS);
+}
+
 // MFMA slots of one k-step of a wave that owns WA blocks: block a outermost, A slice i ascending, B slice j descending
 // over the pairs with D0 <= i + j < D0 + ND, i + j <= S - 1
 template <int S, int D0, int ND, int WA>
@@ -122,6 +152,7 @@ constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..
 constexpr int VARW_BAND4 = 16;     // measurement: XCD patch of 4 (M) x 8 (N) tiles instead of 8 x 4
 constexpr int VARW_BAND16 = 32;    // measurement: 16 x 2
 constexpr int VARW_K64 = 8192;     // k64 tile: v_mfma_i32_16x16x64_i8, one slice product over 64 k per instruction (slice_gemm_y_tile.h)
+constexpr int VARW_BREG = 16384;   // k64 tile: B fragments global -> VGPR (two register sets) instead of through a wave-private LDS stage
 constexpr int VARW_X16 = 4096;     // paired tile: v_mfma_i32_16x16x64_i8, two slice products per instruction (slice_gemm_x_tile.h)
 
 // One output tile of (32*WA) x 128: rows start at A row-block rb0, columns at B row-block 4*tn.

@@ -37,6 +37,15 @@ __device__ __forceinline__ void mfma16_agpr(v4i &c, const v4i &b, const v4i &a) 
 __device__ __forceinline__ void mfma16_vgpr(v4i &c, const v4i &b, const v4i &a) {
   asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c) : "v"(b), "v"(a));
 }
+// B operand in the named registers v[REG : REG + 3] (VARW_BREG, slice_gemm_w_kernel.h)
+template <int REG>
+__device__ __forceinline__ void mfma16_agpr_named(v4i &c, const v4i &a) {
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, v[%c2:%c3], %1, %0" : "+a"(c) : "v"(a), "i"(REG), "i"(REG + 3) : OZ_BREG_CLOBBERS);
+}
+template <int REG>
+__device__ __forceinline__ void mfma16_vgpr_named(v4i &c, const v4i &a) {
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, v[%c2:%c3], %1, %0" : "+v"(c) : "v"(a), "i"(REG), "i"(REG + 3) : OZ_BREG_CLOBBERS);
+}
 // the same behind a VALU write of an operand (ZA's v_cndmask): hipcc pads nothing in front of an asm statement, the two
 // wait states a VALU result needs before an MFMA reads it as A/B are inside the string (guide 5.7 item 2)
 __device__ __forceinline__ void mfma16_agpr_after_valu(v4i &c, const v4i &b, const v4i &a) {

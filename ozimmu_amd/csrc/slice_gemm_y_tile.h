@@ -16,6 +16,15 @@
 // i.e. one per-lane offset (g >> 1) * SL KiB + (g & 1) * 512 + r * 16 for A and B alike (SL = staged slices).  Single-pass modes
 // and the FIRST diagonal pass of the two-pass modes (diagonals 0 .. ND-1 need the slices 0 .. ND-1 only: the staged run of a
 // k-block is then the first SL of its S blocks); an even number of k-blocks per pass.
+//
+// VARW_BREG (round 4): the B row-block of a wave is read by that wave alone, and the planes already hold it in fragment order
+// (16 bytes per lane), so staging it through LDS is a round trip for nothing: 72 of the 108 KiB a step stages at S = 9, written
+// to LDS by the DMA and read straight back.  With VARW_BREG the 2 * S B fragments of the NEXT step are loaded global -> VGPR
+// (global_load_dwordx4, 4 runs of 256 contiguous bytes per instruction) into a second register set while the current step
+// multiplies out of the first; steps alternate between the two sets (the step function is instantiated for both parities, no
+// register copies; the sets are named registers, slice_gemm_w_kernel.h: OZ_BREG_FIRST).  LDS then holds the two shared A stages only (72 KiB at S = 9), a step writes a third of the bytes to LDS
+// and reads two thirds of the fragments from it.  The loads are inline asm like the LDS-DMA copies and ordered by the same
+// counted vmcnt; registers: 16 * WA * S accumulators + 2 * (2 * S * 4) for B: fits WA = 2 up to S = 9.
 #pragma once
 
 namespace ozhip {
@@ -71,7 +80,8 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
 #define YC (kYSched<ND, WA>)
   constexpr int SL = ND, MA = YC.MA, KSL = 2 * SL; // staged slices; staged blocks per row-block and step
   constexpr int NA = 2, PD = 1;
-  constexpr int NB = (VARW & VARW_B1) ? 1 : 2;
+  constexpr bool BREG = (VARW & VARW_BREG) != 0;
+  constexpr int NB = BREG ? 0 : (VARW & VARW_B1) ? 1 : 2;
   static_assert((VARW & VARW_NA3) == 0, "k64 tile: two A buffers (prefetch distance 1)");
   constexpr int A_STAGE = WA * KSL * FRAG_BYTES;
   constexpr int B_STAGE = 4 * KSL * FRAG_BYTES;
@@ -104,7 +114,10 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     a_lds[t] = q * FRAG_BYTES;
   }
   const int8_t *b_src = uniform_ptr(p.b_planes + (size_t)(4u * tn + wave) * rb_stride + pass0);
-  const uint32_t lds0 = (uint32_t)(size_t)((OZ_AS3 char *)smem);
+  // LDS pointers stay in address space 3 (a generic pointer derived from the dynamic LDS symbol makes hipcc emit a null check
+  // against src_shared_base in some instantiations, which its own verifier then rejects: "Operand has incorrect register class")
+  OZ_AS3 char *const lds = (OZ_AS3 char *)smem;
+  const uint32_t lds0 = (uint32_t)(size_t)lds;
   const uint32_t ldsb0 = lds0 + OFF_B + wave * (KSL * FRAG_BYTES);
   auto copy_a = [&](int t, uint32_t voff, uint32_t lds_a) {
     if constexpr (NO_GLOBAL) return;
@@ -118,11 +131,27 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     constexpr int g0 = s / G * G;
     glds16<(s % G) * FRAG_BYTES>(b_src + (kbl * S + g0) * FRAG_BYTES, voff, lds_b, (uint32_t)((kbl * SL + g0) * FRAG_BYTES));
   };
-  auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kstep) {
+  // VARW_BREG: B fragment (b, j) of step `kstep`, k-group g = lane >> 4, row r = lane & 15: byte
+  //   ((2 kstep + (g >> 1)) * S + j) KiB + (g & 1) * 512 + (16 b + r) * 16   of the wave's row-block
+  const uint32_t vG = (uint32_t)(((lane >> 4) >> 1) * (S * FRAG_BYTES) + ((lane >> 4) & 1) * 512 + (lane & 15) * 16);
+  static_assert(!BREG || OZ_BREG_FIRST + 16 * SL <= 256, "two register sets of 2 * SL fragments in v[OZ_BREG_FIRST : 255]");
+  auto load_b = [&](auto cc, uint32_t kstep, auto set) {
+    constexpr int c = decltype(cc)::value;          // in the order the next step needs them: j descending, b
+    constexpr int j = SL - 1 - c / 2, b = c & 1;
+    constexpr int G = 4, g0 = j / G * G;            // slices per immediate-offset group (offset < 4096)
+    constexpr int REG = OZ_BREG_FIRST + ((decltype(set)::value * 2 + b) * SL + j) * 4;
+    if constexpr (!NO_GLOBAL) {
+      const uint32_t voff = vG + kstep * (uint32_t)(2 * S * FRAG_BYTES);
+      gload16_named<REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
+    }
+  };
+  auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kstep, auto bnext) { // bnext: register set (VARW_BREG)
     constexpr int c = decltype(cc)::value;
     const uint32_t voff = lane_off + kstep * (uint32_t)(2 * S * FRAG_BYTES);
     if constexpr (c < NQA) {
       copy_a(c, voff, lds0 + abuf * A_STAGE);
+    } else if constexpr (BREG) {
+      load_b(std::integral_constant<int, c - NQA>{}, kstep, bnext);
     } else {
       // one B buffer: the copy overwrites what this step's B fragments were read from; those reads were issued a step's
       // tail ago, the wait makes "they have returned" a guarantee
@@ -149,6 +178,13 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     else
       mfma16_vgpr(accV[X - 64], b, a);
   };
+  auto mfma_named = [&](auto xc, auto reg, const v4i &a) { // B operand in the named registers (VARW_BREG)
+    constexpr int X = decltype(xc)::value, REG = decltype(reg)::value;
+    if constexpr (X < 64)
+      mfma16_agpr_named<REG>(accA[X], a);
+    else
+      mfma16_vgpr_named<REG>(accV[X - 64], a);
+  };
 
   // ---- circular K (in 64-k steps) with the per-XCD phase hint -----------------------------------------------------
   const uint32_t nk = (p.kb1 - p.kb0) >> 1;
@@ -156,9 +192,9 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   uint32_t koff = 0;
   if (phase && 2u * nk > p.phase_min_kb) {
     if (threadIdx.x == 0)
-      *(volatile uint32_t *)smem = __hip_atomic_load(phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *(volatile OZ_AS3 uint32_t *)lds = __hip_atomic_load(phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    koff = (*(volatile uint32_t *)smem + 1u) % nk;
+    koff = (*(volatile OZ_AS3 uint32_t *)lds + 1u) % nk;
     __syncthreads();
   } else {
     phase = nullptr;
@@ -194,61 +230,68 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
                 "the first ring read of the next stage must come after the barrier");
   static_assert(NG >= 2, "at least two groups per step");
   static_assert(DMA0 + (NDMA - 1) * DMAE < XS, "every copy of a stage is issued before the barrier slot");
-  static_assert(NB == 2 || DMA0 + NQA * DMAE >= YC.gfirst[1], "one B buffer: its refill starts behind the step's first group");
+  static_assert(NB != 1 || DMA0 + NQA * DMAE >= YC.gfirst[1], "one B buffer: its refill starts behind the step's first group");
 
   const int g4 = lane >> 4;
   const uint32_t vF = (uint32_t)((g4 >> 1) * (SL * FRAG_BYTES) + (g4 & 1) * 512 + (lane & 15) * 16);
-  const char *la0 = smem + vF;
-  const char *lb0 = smem + OFF_B + wave * (KSL * FRAG_BYTES) + vF;
+  const OZ_AS3 char *la0 = lds + vF;
+  const OZ_AS3 char *lb0 = lds + OFF_B + wave * (KSL * FRAG_BYTES) + vF;
   int abuf = 0, bbuf = 0;
-  v4i bj[2][SL], af[R], af0;
-  auto read_a = [&](auto gc, const char *la) { // A fragment of group g -> af0 (g == 0) or ring slot (g - 1) % R
+  v4i bj[2][SL], af[R], af0; // B fragments [column block][slice] (VARW_BREG: named registers instead)
+  auto read_a = [&](auto gc, const OZ_AS3 char *la) { // A fragment of group g -> af0 (g == 0) or ring slot (g - 1) % R
     constexpr int g = decltype(gc)::value;
-    const v4i f = *(const v4i *)(la + ((YC.g_a[g] >> 1) * KSL + YC.g_i[g]) * FRAG_BYTES + (YC.g_a[g] & 1) * 256);
+    const v4i f = *(const OZ_AS3 v4i *)(la + ((YC.g_a[g] >> 1) * KSL + YC.g_i[g]) * FRAG_BYTES + (YC.g_a[g] & 1) * 256);
     if constexpr (g == 0)
       af0 = f;
     else
       af[(g - 1) % R] = f;
   };
-  auto read_b = [&](int b, int j, const char *lb) { bj[b][j] = *(const v4i *)(lb + j * FRAG_BYTES + b * 256); };
+  auto read_b = [&](int b, int j, const OZ_AS3 char *lb) { bj[b][j] = *(const OZ_AS3 v4i *)(lb + j * FRAG_BYTES + b * 256); };
 
   // ---- prologue -----------------------------------------------------------------------------------------------
   uint32_t k_issue = koff;
   if (0u < nk) {
-    static_for<NDMA>([&](auto cc) { copy_n(cc, 0, 0, k_issue); });
+    static_for<NDMA>([&](auto cc) { copy_n(cc, 0, 0, k_issue, std::integral_constant<int, 0>{}); });
     k_issue = koff_next(k_issue);
   }
   if constexpr (!NO_GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (!MFMA_ONLY) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (!BREG) {
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+      for (int b = 0; b < 2; b++)
 #pragma unroll
-      for (int j = 0; j < SL; j++) read_b(b, j, lb0);
+        for (int j = 0; j < SL; j++) read_b(b, j, lb0);
+    }
     static_for<(R < NG ? R : NG)>([&](auto gc) { read_a(gc, la0); });
   }
   asm volatile("s_nop 7" ::: "memory"); // zero-fill -> first MFMA reading it as C
 
   uint32_t it = 0;
-  auto step = [&](auto pf_tag, auto nx_tag) {
+  // PAR (VARW_BREG): the register set this step multiplies out of; the next step's fragments are loaded into the other one
+  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag) {
     constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value;
+    constexpr int PC = BREG ? decltype(par_tag)::value : 0, PN = BREG ? (PC ^ 1) : 0;
     const int abuf_n = abuf ^ 1;
     const int abuf_pf = abuf_n, bbuf_pf = NB == 1 ? 0 : (bbuf ^ 1);
     const uint32_t kb_pf = k_issue;
     if constexpr (PF) k_issue = koff_next(k_issue);
-    const char *la = la0 + abuf * A_STAGE;
-    const char *la_n = la0 + abuf_n * A_STAGE;
-    const char *lb_n = lb0 + (NB == 1 ? 0 : (bbuf ^ 1) * B_STAGE);
+    const OZ_AS3 char *la = la0 + abuf * A_STAGE;
+    const OZ_AS3 char *la_n = la0 + abuf_n * A_STAGE;
+    const OZ_AS3 char *lb_n = lb0 + (NB == 1 ? 0 : (bbuf ^ 1) * B_STAGE);
     static_for<NS>([&](auto sc) {
       constexpr int s = decltype(sc)::value;
       constexpr int g = YC.sg[s];
       if constexpr (s == XS && NX && !MFMA_ONLY) {
-        if constexpr (!NO_GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the buffer this barrier releases is refilled right behind it
-        __builtin_amdgcn_s_barrier();
+        // (STAG >= 100, tools/gemm_ablate.hip only, WRONG RESULTS: bit 0 drops the vmcnt wait, bit 1 the lgkmcnt wait, bit 2 the
+        // barrier - what each of them costs a step)
+        constexpr int ABL = STAG >= 100 ? STAG / 100 : 0;
+        if constexpr (!NO_GLOBAL && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the buffer this barrier releases is refilled right behind it
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (STAG > 0)
+        if constexpr (STAG > 0 && STAG < 100)
           for (int q = 0; q < wave; q++) asm volatile("s_nop %0" ::"n"(STAG - 1));
         read_a(std::integral_constant<int, 0>{}, la_n);
         __builtin_amdgcn_sched_barrier(0);
@@ -264,22 +307,27 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
         }
       }
       if constexpr (PF && s >= DMA0 && (s - DMA0) % DMAE == 0 && (s - DMA0) / DMAE < NDMA) {
-        copy_n(std::integral_constant<int, (s - DMA0) / DMAE>{}, abuf_pf, bbuf_pf, kb_pf);
+        copy_n(std::integral_constant<int, (s - DMA0) / DMAE>{}, abuf_pf, bbuf_pf, kb_pf, std::integral_constant<int, PN>{});
         __builtin_amdgcn_sched_barrier(0);
       }
       constexpr int a = YC.sa[s], i = YC.si[s], j = YC.sj[s], b = YC.sb[s];
       constexpr int X = (a * 2 + b) * ND + (i + j);
       if constexpr (MFMA_ONLY)
         mfma(std::integral_constant<int, X>{}, cf[j], cf[i]);
+      else if constexpr (BREG)
+        mfma_named(std::integral_constant<int, X>{}, std::integral_constant<int, OZ_BREG_FIRST + ((PC * 2 + b) * SL + j) * 4>{},
+                   g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       else
         mfma(std::integral_constant<int, X>{}, bj[b][j], g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       if constexpr (s >= XS && NX && !MFMA_ONLY) {
-        constexpr int NREF = 2 * (SL - JT);                 // fragments refreshed behind the barrier
-        constexpr int RPT = (NREF + TAIL - 1) / TAIL;
+        if constexpr (!BREG) {
+          constexpr int NREF = 2 * (SL - JT);                 // fragments refreshed behind the barrier
+          constexpr int RPT = (NREF + TAIL - 1) / TAIL;
 #pragma unroll
-        for (int u = 0; u < RPT; u++) {
-          const int idx = (s - XS) * RPT + u;               // (j descending from S-1, b)
-          if (idx < NREF) read_b(idx & 1, SL - 1 - (idx >> 1), lb_n);
+          for (int u = 0; u < RPT; u++) {
+            const int idx = (s - XS) * RPT + u;               // (j descending from S-1, b)
+            if (idx < NREF) read_b(idx & 1, SL - 1 - (idx >> 1), lb_n);
+          }
         }
         if constexpr (s == XS + 1 || (TAIL == 1 && s == XS))
           if (phase && (it & 1u) == 0 && threadIdx.x == 0)
@@ -289,10 +337,12 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     });
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NX && !MFMA_ONLY) {
+      if constexpr (!BREG) {
 #pragma unroll
-      for (int j = JT - 1; j >= 0; j--)
+        for (int j = JT - 1; j >= 0; j--)
 #pragma unroll
-        for (int b = 0; b < 2; b++) read_b(b, j, lb_n);
+          for (int b = 0; b < 2; b++) read_b(b, j, lb_n);
+      }
       static_for<R - 1>([&](auto qc) {
         constexpr int q = decltype(qc)::value + 1;
         if constexpr (NRP + q - R + 1 > NG - 1 && q < NG) read_a(std::integral_constant<int, q>{}, la_n);
@@ -303,9 +353,28 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     abuf = abuf_n;
     bbuf ^= 1;
   };
-  for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{});
-  for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{});
-  for (; it < nk; it++) step(std::false_type{}, std::false_type{});
+  if constexpr (BREG) {
+    // Two steps per iteration, one per register set, as straight-line code (a branch on the step's parity inside the loop makes
+    // hipcc assign the accumulators differently on the two sides and shuffle ~300 registers at every join), and ONE form of
+    // the step: the last step of a tile prefetches like any other - the circular k walk wraps to the tile's first stage, so the
+    // addresses are valid and the data is dropped (one stage of extra L2 traffic per tile: 1 / 128 at K = 8192) - instead of
+    // a second pair of step bodies whose entry costs another round of register shuffling.  The host launches this form for
+    // an even number of steps only (slice_gemm_launch.h).
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    for (; it < nk;) {
+      step(std::true_type{}, std::true_type{}, P0{});
+      it++;
+      step(std::true_type{}, std::true_type{}, P1{});
+      it++;
+    }
+  } else {
+    using P0 = std::integral_constant<int, 0>;
+    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{});
+    if constexpr (PD > 1)
+      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{});
+    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{});
+  }
 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulator
   auto acc = [&](int a, int b, int d, int v) -> int {

@@ -42,3 +42,17 @@ def oz():
     yield ozimmu_amd, h
     torch.cuda.synchronize()
     ozimmu_amd.destroy(h)
+
+
+@pytest.fixture(scope="session")
+def ozh():
+    """the bindings over libozimmu_hip_test.so (-DOZIMMU_HIP_TEST_HOOKS) + a handle of that library: for the tests that read
+    the kernels' INT32 diagonal sums, inject a failed launch or jump the exponent epoch.  Every other test uses `oz`, the
+    library that ships."""
+    import torch  # noqa: F401
+    import ozimmu_amd
+    t = ozimmu_amd.test_flavour()
+    h = t.create()
+    yield t, h
+    torch.cuda.synchronize()
+    t.destroy(h)

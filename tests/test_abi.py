@@ -66,11 +66,29 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"{name} is declared in include/ozimmu_hip.h but not exported"
 
 
-def test_exports_are_unmangled_c_symbols():
-    out = subprocess.check_output(["nm", "-D", "--defined-only", ozimmu_amd.LIB_PATH], text=True)
+@pytest.mark.parametrize("flavour", ["product", "test"])
+def test_exports_are_unmangled_c_symbols(lib, flavour):
+    """both flavours of the library (ozimmu_amd/build.py) export the same C ABI: what ships, and the build with the test hooks"""
+    path = ozimmu_amd.LIB_PATH if flavour == "product" else ozimmu_amd.TEST_LIB_PATH
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
     for name in declared_functions() + INTERPOSED:
         assert name in exported
+
+
+def test_bindings_load_the_library_that_ships(lib):
+    """`ozimmu_amd.lib()` - what bench.py, smoke() and the parity tests run - is libozimmu_hip.so, built WITHOUT
+    -DOZIMMU_HIP_TEST_HOOKS: its hook entry points say so, and the hook environment variables are not even read"""
+    assert os.path.basename(ozimmu_amd.LIB_PATH) == "libozimmu_hip.so" or os.environ.get("OZIMMU_HIP_LIBRARY")
+    lib.ozimmu_hip_tile_plan.restype = ctypes.c_int
+    lib.ozimmu_hip_tile_plan.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_double)]
+    out = (ctypes.c_double * 3)()
+    assert lib.ozimmu_hip_tile_plan(512, 512, 2, 256, 1, out) == 2          # the literal simulation is a test hook
+    blob = open(ozimmu_amd.LIB_PATH, "rb").read()
+    hooked = open(ozimmu_amd.TEST_LIB_PATH, "rb").read()
+    for name in (b"OZIMMU_HIP_TEST_FAIL_LAUNCH", b"OZIMMU_HIP_TEST_EXP_EPOCH", b"OZIMMU_HIP_TEST_NO_STREAM_ORDER"):
+        assert name not in blob and name in hooked
 
 
 def test_interposed_surface_covers_the_vendor_fp64_gemm_exports():
@@ -167,10 +185,11 @@ def test_product_has_no_cpu_fallback():
 
 def test_tile_plan_closed_form_matches_the_literal_dispatch_simulation(lib):
     """csrc/tile_plan.h: the per-call row partition is searched with a closed-form makespan (microseconds for a
-    32768 x 32768 output); the test build also carries the literal round-by-round simulation it replaced - same
+    32768 x 32768 output); the test flavour also carries the literal round-by-round simulation it replaced - same
     partition, same makespan, on shapes from one tile to 131072 tiles.  Host arithmetic only."""
     import random
     import time
+    lib = ozimmu_amd.test_flavour().lib()
     lib.ozimmu_hip_tile_plan.restype = ctypes.c_int
     lib.ozimmu_hip_tile_plan.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_double)]

@@ -294,6 +294,39 @@ def test_pytorch_batched_matmul_is_intercepted():
     assert "-m1100-n1050-k1024-batch_count3]" in out or "-m1050-n1100-k1024-batch_count3]" in out, out
 
 
+def test_pytorch_conjugate_transposed_complex_matmul_is_intercepted():
+    """torch: A.mH @ B (complex128) -> hipblasZgemm with HIPBLAS_OP_C -> rocblas_zgemm(conjugate_transpose) -> the shim runs it
+    on the Ozaki path as OZIMMU_OP_C.  The reference's hook maps CUBLAS_OP_C to op_t (src/cublas.cu:50-56) and would return
+    A^T B; round 3 passed such calls through to the vendor.  fp64_int8_3 is visibly coarse: proof that the call was intercepted."""
+    code = textwrap.dedent("""
+        import torch
+        torch.manual_seed(0)
+        a = torch.complex(torch.rand(1024, 1100, dtype=torch.float64, device="cuda") * 2 - 1,
+                          torch.rand(1024, 1100, dtype=torch.float64, device="cuda") * 2 - 1)
+        b = torch.complex(torch.rand(1024, 1050, dtype=torch.float64, device="cuda") * 2 - 1,
+                          torch.rand(1024, 1050, dtype=torch.float64, device="cuda") * 2 - 1)
+        c = a.mH @ b
+        d = a.mH @ b.mH.mH.clone()
+        e = (b.mH @ a).mH            # = a^H b again, through the other operand
+        torch.cuda.synchronize()
+        ref = a.cpu().mH @ b.cpu()
+        wrong = a.cpu().mT @ b.cpu()
+        print("MAXDIFF %.3e %.3e %.3e" % ((c.cpu() - ref).abs().max().item(), (e.cpu() - ref).abs().max().item(),
+                                          (c.cpu() - wrong).abs().max().item()))
+    """)
+    diffs = {}
+    for mode in ("fp64_int8_3", "fp64_int8_10"):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
+        e.update(LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE=mode, OZIMMU_INFO="1")
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stdout + p.stderr
+        line = [l for l in p.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()
+        diffs[mode] = tuple(float(x) for x in line[1:4])
+    assert diffs["fp64_int8_3"][0] > 1e-6 and diffs["fp64_int8_3"][1] > 1e-6, diffs      # intercepted (3 slices are coarse)
+    assert diffs["fp64_int8_10"][0] < 1e-10 and diffs["fp64_int8_10"][1] < 1e-10, diffs    # and conjugated
+    assert diffs["fp64_int8_10"][2] > 1.0, diffs                                            # not the plain transpose
+
+
 def test_pytorch_cuda_graph_capture_through_the_preload():
     """torch.cuda.graph around float64 matmuls under LD_PRELOAD: after an eager warm-up (workspace allocated) the captured
     call is the Ozaki path's kernels (fp64_int8_3 is visibly coarse, so a replay that ran the vendor DGEMM would show);

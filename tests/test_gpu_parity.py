@@ -106,9 +106,9 @@ def test_split_special_rows(oz):
 @pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
 @pytest.mark.parametrize("m,n,k,S", [(64, 64, 32, 3), (100, 70, 130, 6), (65, 129, 257, 9), (33, 31, 65, 13),
                                      (40, 50, 40, 18)])
-def test_diagonal_sums_bit_exact(oz, op_a, op_b, m, n, k, S):
+def test_diagonal_sums_bit_exact(ozh, op_a, op_b, m, n, k, S):
     import torch
-    m_, h = oz
+    m_, h = ozh   # the INT32 dump is a test hook: libozimmu_hip_test.so
     rng = np.random.default_rng(m * 7 + n * 3 + k + S)
     a = operand(op_a, m, k, rng, fill=exp_rand(2.0))
     b = operand(op_b, k, n, rng, fill=exp_rand(2.0))
@@ -204,6 +204,26 @@ def test_gemm_k_chunking_large_k(oz):
     np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
 
 
+@pytest.mark.parametrize("k", [22145, 22176, 22177])
+def test_gemm_k_at_the_pass_boundary(oz, k):
+    """S = 6, L = 7: 2^31 / (6 * 127^2) = 22190 k fit one pass, i.e. 693 k-blocks - an odd count, while the planes hold an
+    even one (694 for K = 22145..22176).  The library's pass length is a multiple of 64 k (22144), so these K take two
+    chained passes AND get an FP64 workspace for them (round 3 sized the workspace for one pass and then ran two: ADVICE r3)"""
+    m_, h = oz
+    m, n, S = 40, 72, 6
+    assert O.bits_per_int8(k) == 7
+    rng = np.random.default_rng(k)
+    a = operand("T", m, k, rng)
+    b = operand("N", k, n, rng)
+    c = ColMajor(m, n)
+    c_ref = ColMajor(m, n)
+    assert _run_gemm(m_, h, "T", "N", m, n, k, 1.0, a, b, 0.0, c, "fp64_int8_6") == 0
+    kchunk = (2147483647 // (S * 127 * 127)) // 64 * 64
+    assert kchunk == 22144
+    O.gemm("T", "N", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL, kchunk=kchunk)
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
 @pytest.mark.parametrize("m,n,k,S", [(40, 24, 140000, 9), (40, 24, 140000, 14), (24, 24, 530000, 9)])
 def test_gemm_narrow_slices_for_very_long_k(oz, m, n, k, S):
     """k > 2^17 -> 6-bit slices, k > 2^19 -> 5-bit slices (get_bits_per_int8, src/split.cu:520-536); the INT32-safe
@@ -292,9 +312,10 @@ def _dev_colmajor(arr):
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
-def test_hip_path_reproduces_golden(oz, path):
+def test_hip_path_reproduces_golden(oz, ozh, path):
     import torch
     m_, h = oz
+    mt_, ht = ozh   # only the INT32 diagonal sums come from the test flavour; slices and the FP64 result from the product
     g = np.load(path)
     op_a, op_b = str(g["op_a"]), str(g["op_b"])
     m, n, k, S, L = (int(g[x]) for x in ("m", "n", "k", "S", "L"))
@@ -313,9 +334,10 @@ def test_hip_path_reproduces_golden(oz, path):
         np.testing.assert_array_equal(mx.cpu().numpy().view(np.uint64), ref_e.view(np.uint64))
     # INT32 diagonal sums
     d = torch.zeros((S, n, m), dtype=torch.int32, device="cuda")
-    assert m_.diagonal_sums(h, op_a, op_b, m, n, k, a, lda, b, ldb, S, d) == 0
+    assert mt_.diagonal_sums(ht, op_a, op_b, m, n, k, a, lda, b, ldb, S, d) == 0
     _sync()
     np.testing.assert_array_equal(d.cpu().numpy().transpose(0, 2, 1).astype(np.int64), g["diag"])
+    assert m_.diagonal_sums(h, op_a, op_b, m, n, k, a, lda, b, ldb, S, d) == 2   # the product carries no dump hook
     # FP64 result, bit-exact in the kernel's grouping; a few ulp of the partial-sum scale from the reference's
     c, ldc = _dev_colmajor(np.asfortranarray(g["c0"]))
     assert m_.gemm(h, op_a, op_b, m, n, k, float(g["alpha"]), a, lda, b, ldb, float(g["beta"]), c, ldc,

@@ -141,10 +141,10 @@ def test_two_host_threads_two_streams_share_one_handle(oz):
 
 # ---------------------------------------------------------------- error paths
 
-def test_injected_launch_failure_real_leaves_c_untouched(oz, monkeypatch):
+def test_injected_launch_failure_real_leaves_c_untouched(ozh, monkeypatch):
     """status 3 = failed before C was written: the caller (the interposer) may fall back to the vendor GEMM"""
     import torch
-    m_, h = oz
+    m_, h = ozh   # launch-failure injection is a test hook: libozimmu_hip_test.so
     n = 128
     a = torch.rand(n, n, dtype=torch.float64, device="cuda")
     c = torch.full((n, n), 7.0, dtype=torch.float64, device="cuda")
@@ -161,10 +161,10 @@ def test_injected_launch_failure_real_leaves_c_untouched(oz, monkeypatch):
     assert m_.gemm(h, "N", "N", n, n, n, 1.0, a, n, a, n, 0.5, c, n, "fp64_int8_9") == 0
 
 
-def test_injected_launch_failure_complex_reports_modified_c(oz, monkeypatch):
+def test_injected_launch_failure_complex_reports_modified_c(ozh, monkeypatch):
     """the complex path scales C by beta before its four products: a later failure is status 4, never 3"""
     import torch
-    m_, h = oz
+    m_, h = ozh
     n = 96
     a = torch.view_as_complex(torch.rand(n, n, 2, dtype=torch.float64, device="cuda"))
     c = torch.view_as_complex(torch.rand(n, n, 2, dtype=torch.float64, device="cuda"))
@@ -213,7 +213,7 @@ def test_preload_fallback_only_when_c_is_untouched(tmp_path):
     e = {k: v for k, v in os.environ.items() if not k.startswith("OZIMMU_")}
     e.update(LD_PRELOAD=ozimmu_amd.LIB_PATH, OZIMMU_COMPUTE_MODE="fp64_int8_9", OZIMMU_INTERCEPT_THRESHOLD_M="64",
              OZIMMU_INTERCEPT_THRESHOLD_N="64", OZIMMU_INTERCEPT_THRESHOLD_K="64")
-    e1 = dict(e, OZIMMU_HIP_TEST_FAIL_LAUNCH="1")
+    e1 = dict(e, OZIMMU_HIP_TEST_FAIL_LAUNCH="1", LD_PRELOAD=ozimmu_amd.TEST_LIB_PATH)  # the injection is a test hook
     p = subprocess.run([str(exe)], env=e1, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DGEMM status=0 c00=65.000000" in p.stdout, p.stdout           # vendor fallback, beta applied once
@@ -460,7 +460,8 @@ def test_exponent_word_epoch_wraps_around(monkeypatch):
     rows that write nothing) must stay bit-exact across it"""
     import torch
     monkeypatch.setenv("OZIMMU_HIP_TEST_EXP_EPOCH", str((1 << 21) - 4))
-    h = ozimmu_amd.create()
+    oz_t = ozimmu_amd.test_flavour()   # the epoch jump is a test hook: libozimmu_hip_test.so
+    h = oz_t.create()
     try:
         rng = np.random.default_rng(99)
         for it, (m, n, k) in enumerate([(300, 200, 64), (90, 70, 33), (300, 200, 64), (64, 260, 100), (90, 70, 33),
@@ -473,13 +474,13 @@ def test_exponent_word_epoch_wraps_around(monkeypatch):
             a._dev = None
             c = ColMajor(m, n)
             c_ref = ColMajor(m, n)
-            assert ozimmu_amd.gemm(h, "N", "T", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, "fp64_int8_8") == 0
+            assert oz_t.gemm(h, "N", "T", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld, "fp64_int8_8") == 0
             torch.cuda.synchronize()
             assert O.gemm("N", "T", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, 8, O.ORDER_DIAGONAL) == 0
             np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64), err_msg=f"call {it}")
     finally:
         torch.cuda.synchronize()
-        ozimmu_amd.destroy(h)
+        oz_t.destroy(h)
 
 
 def test_epoch_wrap_around_with_a_captured_graph_in_flight(monkeypatch):
@@ -498,7 +499,8 @@ def test_epoch_wrap_around_with_a_captured_graph_in_flight(monkeypatch):
     assert O.gemm("N", "T", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL) == 0
     assert O.gemm("N", "T", m, n, k, 1.0, a2.view, b.view, 0.0, c2_ref.view, S, O.ORDER_DIAGONAL) == 0
     monkeypatch.setenv("OZIMMU_HIP_TEST_EXP_EPOCH", str((1 << 21) - 6))
-    h = ozimmu_amd.create()
+    oz_t = ozimmu_amd.test_flavour()   # the epoch jump is a test hook: libozimmu_hip_test.so
+    h = oz_t.create()
     try:
         s = torch.cuda.Stream()
         c = torch.zeros(n, m, dtype=torch.float64, device="cuda")
@@ -508,7 +510,7 @@ def test_epoch_wrap_around_with_a_captured_graph_in_flight(monkeypatch):
 
         def eager(src, dst, ref, tag):
             with torch.cuda.stream(s):
-                assert ozimmu_amd.gemm_on_stream(h, s, "N", "T", m, n, k, 1.0, src.dev, src.ld, b.dev, b.ld, 0.0, dst, m,
+                assert oz_t.gemm_on_stream(h, s, "N", "T", m, n, k, 1.0, src.dev, src.ld, b.dev, b.ld, 0.0, dst, m,
                                                  f"fp64_int8_{S}") == 0
             torch.cuda.synchronize()
             np.testing.assert_array_equal(dst.cpu().numpy().view(np.uint64), ref.buf.view(np.uint64), err_msg=tag)
@@ -517,7 +519,7 @@ def test_epoch_wrap_around_with_a_captured_graph_in_flight(monkeypatch):
         monkeypatch.delenv("OZIMMU_HIP_TEST_EXP_EPOCH")     # from here on the epoch runs freely
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):                 # captured with tag 2^21 - 4
-            st = ozimmu_amd.gemm_on_stream(h, torch.cuda.current_stream(), "N", "T", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld,
+            st = oz_t.gemm_on_stream(h, torch.cuda.current_stream(), "N", "T", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld,
                                            0.0, c, m, f"fp64_int8_{S}")
         assert st == 0
         for it in range(8):                                 # the eager epochs run through the wrap at it = 3
@@ -528,4 +530,4 @@ def test_epoch_wrap_around_with_a_captured_graph_in_flight(monkeypatch):
             eager(a2, c2, c2_ref, f"eager {it}")
     finally:
         torch.cuda.synchronize()
-        ozimmu_amd.destroy(h)
+        oz_t.destroy(h)

@@ -32,9 +32,9 @@ def _sync():
 # every S has its own instantiation (WA = 4 for S <= 7, 3 for 8..9, 2 for 10..12; S = 13: 4 + 2; S >= 14: first pass)
 @pytest.mark.parametrize("S", list(range(3, 19)))
 @pytest.mark.parametrize("m,n,k", [(97, 129, 65), (300, 140, 200)])
-def test_wide_diagonal_sums_bit_exact(oz, S, m, n, k):
+def test_wide_diagonal_sums_bit_exact(ozh, S, m, n, k):
     import torch
-    m_, h = oz
+    m_, h = ozh   # the INT32 dump is a test hook: libozimmu_hip_test.so
     rng = np.random.default_rng(m * 7 + n * 3 + k + S)
     a = operand("N", m, k, rng, fill=exp_rand(2.0))
     b = operand("T", k, n, rng, fill=exp_rand(2.0))
@@ -248,11 +248,11 @@ def test_chip_filling_problem_on_emulated_xcd_counts(oz, monkeypatch, xcds):
 # paired / 32x32x32 one)
 @pytest.mark.parametrize("S", [3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 17, 18])
 @pytest.mark.parametrize("m,n,k", [(97, 129, 64), (300, 140, 192), (64, 128, 448), (70, 129, 1120)])
-def test_k64_tile_diagonal_sums_bit_exact(oz, monkeypatch, S, m, n, k):
+def test_k64_tile_diagonal_sums_bit_exact(ozh, monkeypatch, S, m, n, k):
     """the k64 tile function with an even number of k-blocks (2, 6, 14: its own path, not the fallback): INT32 diagonal sums
     bit-exact, every single-pass S it is built for, mixed tile heights and clamped row-blocks"""
     import torch
-    m_, h = oz
+    m_, h = ozh   # the INT32 dump is a test hook: libozimmu_hip_test.so
     monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", "k64")
     rng = np.random.default_rng(m * 5 + n * 3 + k + S)
     a = operand("N", m, k, rng, fill=exp_rand(2.0))

@@ -69,14 +69,40 @@ def test_zgemm_bit_exact_vs_oracle(oz, op_a, op_b, m, n, k, S):
     c = zoperand("N", m, n, rng, pad=3)
     c_ref = ColMajor(m, n, ld=m + 3, dtype=np.complex128)
     c_ref.buf[...] = c.buf
+    c0 = np.array(c.view)
     alpha, beta = 1.25 - 0.5j, -0.75 + 2.0j
     st = m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, f"fp64_int8_{S}", m_.complx)
     _sync()
     assert st == 0
+    a.buf[:, a.rows:] = 0   # (the oracle's conjugated copy walks the padding too)
+    b.buf[:, b.rows:] = 0
     assert O.zgemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
-    got = c.download()
+    got = np.array(c.download())
     np.testing.assert_array_equal(zbits(got), zbits(c_ref.view))
-    assert np.isnan(c.buf[:, m:]).all()                    # padding of C untouched
+    # ... and it IS the conjugate transpose: against numpy on the same data
+    opm = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+    want = alpha * (opm[op_a](a.view) @ opm[op_b](b.view)) + beta * c0
+    if S >= 9:
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-11
+
+
+def test_zgemm_k_at_the_pass_boundary(oz):
+    """the complex twin of test_gpu_parity.py::test_gemm_k_at_the_pass_boundary: S = 6, K = 22176 holds 694 k-blocks against a
+    pass length of 692 - two chained passes per real product, through the FP64 workspace"""
+    m_, h = oz
+    m, n, k, S = 24, 40, 22176, 6
+    rng = np.random.default_rng(k)
+    a = zoperand("N", m, k, rng)
+    b = zoperand("T", k, n, rng)
+    c = zoperand("N", m, n, rng)
+    c_ref = ColMajor(m, n, dtype=np.complex128)
+    c_ref.buf[...] = c.buf
+    alpha, beta = 0.5 + 1.5j, 1.0 - 0.25j
+    assert m_.gemm(h, "N", "T", m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, "fp64_int8_6", m_.complx) == 0
+    _sync()
+    kchunk = (2147483647 // (S * 127 * 127)) // 64 * 64
+    assert O.zgemm("N", "T", m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL, kchunk=kchunk) == 0
+    np.testing.assert_array_equal(zbits(c.download()), zbits(c_ref.view))
 
 
 def test_zgemm_beta_zero_does_not_read_c_and_real_alpha(oz):

@@ -131,3 +131,71 @@ def test_kernels_do_not_spill(asm):
         for name, scratch in metas:
             limit = 128 if ("slice_gemm_w_kernel" in name or "slice_gemm_w_multi_kernel" in name) else 0
             assert int(scratch) <= limit, f"{src}: {name} uses {scratch} bytes of scratch per lane"
+
+
+def test_product_and_test_flavour_kernels_differ_only_in_the_dump_branch():
+    """ozimmu_amd/build.py builds the same sources twice: libozimmu_hip.so (what ships, no hook) and libozimmu_hip_test.so
+    (-DOZIMMU_HIP_TEST_HOOKS).  In the kernels the only hook is the INT32 diagonal-sum dump at the top of the epilogues:
+    same kernels, same MFMA / LDS-DMA / fragment-read / barrier counts in both flavours, and the 4-byte stores of the dump
+    exist in the test flavour only.  (The parity tests that need no hook, bench.py and smoke() run the product.)"""
+    sys.path.insert(0, ROOT)
+    from ozimmu_amd import build as B
+    B.build()
+    pat = {"mfma": r"\bv_mfma_i32_\w+", "lds_dma": r"\bglobal_load_lds_dwordx4\b", "frag": r"\bds_read_b128\b",
+           "barrier": r"\bs_barrier\b"}
+    seen = 0
+    for part in B.GEMM_PARTS:
+        prod = open(B.device_asm_path(part)).read()
+        test = open(B.device_asm_path(part).replace(os.sep + "build" + os.sep, os.sep + "build_test" + os.sep)).read()
+        kp, kt = _kernels(prod, "slice_gemm"), _kernels(test, "slice_gemm")
+        assert kp and set(kp) == set(kt), part
+        for name in kp:
+            for what, rx in pat.items():
+                assert len(re.findall(rx, kp[name])) == len(re.findall(rx, kt[name])), (name, what)
+            assert not re.search(r"\bglobal_store_dword\b", kp[name]), f"{name}: a dump store in the product"
+            assert re.search(r"\bglobal_store_dword\b", kt[name]), f"{name}: no dump store in the test flavour"
+            seen += 1
+    assert seen >= 60
+
+
+def test_named_b_registers_are_untouched_by_the_compiler(asm):
+    """VARW_BREG kernels (slice_gemm_y_tile.h) keep the k64 tile's B fragments in hand-allocated registers v[112:255]: the
+    inline-asm loads write them, the inline-asm MFMAs read them, every such statement lists the range as clobbered.  The
+    compiler may use the range before the first load of a tile function and after its last MFMA (the epilogue), never in
+    between - a compiler-generated instruction there (a spill reload, an address temporary) would corrupt a fragment."""
+    ks = {**_kernels(asm["slice_gemm.hip"], "slice_gemm_w_kernel"), **_kernels(asm["slice_gemm.hip"], "slice_gemm_w_multi_kernel")}
+    breg = {n: b for n, b in ks.items() if "global_load_dwordx4 v[" in b}
+    assert len(breg) >= 2, "no VARW_BREG kernel in the library"
+    for name, body in breg.items():
+        lines = body.split("\n")
+        # regions: from a run's first named load to the last MFMA before compiler code touches ... per tile function: the
+        # kernel holds several tile functions (full / reduced height); a region ends at the last MFMA that precedes the
+        # next "first load" (a load preceded by no MFMA since the previous region's end)
+        in_asm, inside, last_mfma, pending = False, False, -1, []
+        for i, l in enumerate(lines):
+            if "#ASMSTART" in l:
+                in_asm = True
+                continue
+            if "#ASMEND" in l:
+                in_asm = False
+                continue
+            if in_asm:
+                if "global_load_dwordx4 v[" in l:
+                    inside = True
+                if "v_mfma" in l and inside:
+                    last_mfma = i
+                    pending = []          # everything seen so far lies in front of an MFMA of the region: must be clean
+                continue
+            if not inside or l.strip().startswith(";"):
+                continue
+            regs = {int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", l)}
+            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", l):
+                regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            if any(r >= 112 for r in regs):
+                pending.append((i, l.strip()))
+                # a later MFMA of the same region makes this a violation; the epilogue (no MFMA behind it) may use the range
+                rest = "\n".join(lines[i:i + 4000])
+                nxt_mfma = rest.find("v_mfma")
+                nxt_zero = rest.find("v_accvgpr_write")  # the next tile function starts by zero-filling its accumulators
+                assert nxt_mfma < 0 or (0 <= nxt_zero < nxt_mfma), f"{name}: compiler code touches v112+ inside a k loop: {l.strip()}"
+                inside = False             # epilogue reached: the next named load opens the next region

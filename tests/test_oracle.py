@@ -421,3 +421,29 @@ def test_complex_auto_mode_counts_both_parts():
     _, cim = O.auto_select("N", "N", m, n, k, np.asfortranarray(a.imag), np.asfortranarray(b.imag), 1.5)
     np.testing.assert_array_equal(cnt, cre + cim)          # src/split.cu:367-374
     assert s == next(S for S in range(3, 19) if cnt[S - 3] / (m * k + k * n) <= 1.5)
+
+
+@pytest.mark.parametrize("op_a,op_b", [("C", "N"), ("N", "C"), ("C", "C"), ("C", "T")])
+def test_oracle_zgemm_conjugate_transpose(op_a, op_b):
+    """OZ_OP_C: the operand's imaginary part negated, then the reference's op_t path (oracle/ozaki_oracle.h; the reference's
+    hook runs CUBLAS_OP_C as a plain transpose, src/cublas.cu:50-56).  Against numpy's conjugate transpose, and bit-identical
+    to handing the oracle an explicitly conjugated operand with op T."""
+    m, n, k, S = 37, 29, 130, 10
+    rng = np.random.default_rng(5)
+
+    def z(rows, cols):
+        return np.asfortranarray(rng.uniform(-1, 1, (rows, cols)) + 1j * rng.uniform(-1, 1, (rows, cols)))
+    a = z(m, k) if op_a == "N" else z(k, m)
+    b = z(k, n) if op_b == "N" else z(n, k)
+    c0 = z(m, n)
+    alpha, beta = 0.75 + 0.5j, -1.5 + 0.25j
+    c = np.array(c0, order="F")
+    assert O.zgemm(op_a, op_b, m, n, k, alpha, a, b, beta, c, S, O.ORDER_REFERENCE) == 0
+    opm = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+    want = alpha * (opm[op_a](a) @ opm[op_b](b)) + beta * c0
+    assert np.abs(c - want).max() / np.abs(want).max() < 1e-13
+    c2 = np.array(c0, order="F")
+    a2 = np.asfortranarray(a.conj()) if op_a == "C" else a
+    b2 = np.asfortranarray(b.conj()) if op_b == "C" else b
+    assert O.zgemm(op_a.replace("C", "T"), op_b.replace("C", "T"), m, n, k, alpha, a2, b2, beta, c2, S, O.ORDER_REFERENCE) == 0
+    np.testing.assert_array_equal(c.T.copy().view(np.uint64), c2.T.copy().view(np.uint64))

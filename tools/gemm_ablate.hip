@@ -73,7 +73,7 @@ template <int S, int WA, int VARW, int STAG = 0, int DMA0 = -1, int DMAE = 4, in
 static float run_w(const SliceGemmArgs &a0, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   constexpr int NA = (VARW & VARW_NA3) ? 3 : 2;
   constexpr int NBUF_B = (VARW & VARW_B1) ? 1 : 2;
-  constexpr size_t lds = (VARW & VARW_K64) ? (size_t)(2 * WA + 4 * NBUF_B) * (2 * S) * FRAG_BYTES
+  constexpr size_t lds = (VARW & VARW_K64) ? (size_t)(2 * WA + ((VARW & VARW_BREG) ? 0 : 4 * NBUF_B)) * (2 * S) * FRAG_BYTES
                                            : (size_t)(NA * WA + NBUF_B * 4) * S * FRAG_BYTES + ((VARW & VARW_X16) ? 2 * X_PAD : 0);
   SliceGemmArgs a = a0;
   a.tiles_m = (a.M + 32 * WA - 1) / (32 * WA);
@@ -328,6 +328,58 @@ int main(int argc, char **argv) {
     std::sort(v.ms.begin(), v.ms.end());
     const double ops = (double)(S * (S + 1) / 2) * 2.0 * M * N * K;
     printf("S=%d ring %d %-46s median %8.3f ms (%7.1f TOPS)   min %8.3f ms\n", S, OZ_Y_RING, v.name, v.ms[v.ms.size() / 2],
+           ops / v.ms[v.ms.size() / 2] / 1e9, v.ms[0]);
+  }
+  return 0;
+#elif defined(ABLATE_BREG) // -DABLATE_BREG [-DABLATE_S=n]: k64 tile with the B fragments loaded global -> VGPR (VARW_BREG) against the LDS-staged form
+  constexpr int Y = VARW_K64 | VARW_B1, Z = VARW_K64 | VARW_BREG;
+#ifndef ABLATE_BREG_PART
+#define ABLATE_BREG_PART 1
+#endif
+  std::vector<Var> vars = {
+      {"k64 64x128 B via LDS (round 3) dma 8 tail 12", run_w<S, 2, Y, 0, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR dma 8 tail 12", run_w<S, 2, Z, 0, -1, 8, 12, false, true>, false, {}},
+#if ABLATE_BREG_PART == 1 // (a kernel instantiation compiles for a minute: two binaries, built side by side)
+      {"k64 64x128 B->VGPR dma 8 tail 6", run_w<S, 2, Z, 0, -1, 8, 6, false, true>, false, {}},
+      {"k64 64x128 B->VGPR dma 8 tail 20", run_w<S, 2, Z, 0, -1, 8, 20, false, true>, false, {}},
+      {"k64 64x128 B->VGPR no copies", run_w<S, 2, Z | VARW_NO_GLOBAL, 0, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B via LDS no copies", run_w<S, 2, Y | VARW_NO_GLOBAL, 0, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 mfma only", run_w<S, 2, Y | VARW_MFMA_ONLY, 0, -1, 8, 12, false, true>, false, {}},
+#elif ABLATE_BREG_PART == 3 // what the step's waits cost (wrong results)
+      {"k64 64x128 B->VGPR without the vmcnt wait", run_w<S, 2, Z, 100, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR without the lgkmcnt wait", run_w<S, 2, Z, 200, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR without the barrier", run_w<S, 2, Z, 400, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR without all three", run_w<S, 2, Z, 700, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR no copies, without all three", run_w<S, 2, Z | VARW_NO_GLOBAL, 700, -1, 8, 12, false, true>, false, {}},
+#else
+      {"k64 64x128 B->VGPR dma 4 tail 12", run_w<S, 2, Z, 0, -1, 4, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR dma 6 tail 12", run_w<S, 2, Z, 0, -1, 6, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR dma 10 tail 12", run_w<S, 2, Z, 0, -1, 10, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR dma 12 tail 12", run_w<S, 2, Z, 0, -1, 12, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR dma 8 from slot 2 tail 12", run_w<S, 2, Z, 0, 2, 8, 12, false, true>, false, {}},
+#endif
+  };
+  for (int r = 0; r < rounds + 1; r++)
+    for (auto &v : vars) {
+      const float ms = v.fn(a, st, e0, e1);
+      if (r > 0) v.ms.push_back(ms);
+    }
+  { // bitwise cross-check against the LDS-staged form
+    std::vector<double> c0(M * N), c1(M * N);
+    CK(hipMemset(C, 0xFF, 8 * M * N));
+    run_w<S, 2, Y, 0, -1, 8, 12, false, true>(a, st, e0, e1);
+    CK(hipMemcpy(c0.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
+    CK(hipMemset(C, 0xFF, 8 * M * N));
+    run_w<S, 2, Z, 0, -1, 8, 12, false, true>(a, st, e0, e1);
+    CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < M * N; i++) bad += std::memcmp(&c0[i], &c1[i], 8) != 0;
+    std::printf("k64 B->VGPR vs k64 B via LDS: %zu mismatching elements of %zu\n", bad, M * N);
+  }
+  for (auto &v : vars) {
+    std::sort(v.ms.begin(), v.ms.end());
+    const double ops = (double)(S * (S + 1) / 2) * 2.0 * M * N * K;
+    printf("S=%d %-48s median %8.3f ms (%7.1f TOPS)   min %8.3f ms\n", S, v.name, v.ms[v.ms.size() / 2],
            ops / v.ms[v.ms.size() / 2] / 1e9, v.ms[0]);
   }
   return 0;
