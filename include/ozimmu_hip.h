@@ -90,6 +90,11 @@ typedef enum { OZIMMU_MATRIX_A = 0, OZIMMU_MATRIX_B = 1 } ozimmu_matrix_t;      
 
 /* ozimmu.hpp:48-49 (src/handle.cu:6-52).  Return 0 on success. */
 int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm);
+/* What the launch policy knows about the handle's device (probed once per device at the first create): out[0] = CUs,
+ * out[1] = XCDs (L2 domains), out[2] = the time in us of one v_mfma_i32_32x32x32_i8 under sustained full-entropy load that the
+ * policy plans with (the measured value clamped to +-25 % of the nominal 0.0194), out[3] = the measured value itself.  No
+ * counterpart in the reference (it has no kernel choice: src/gemm.cu:315-329 calls cuBLAS). */
+int ozimmu_hip_device_info(ozimmu_hip_handle_t handle, double out[4]);
 int ozimmu_hip_destroy(ozimmu_hip_handle_t handle);
 
 /* ozimmu.hpp:50-51 set_cuda_stream (src/handle.cu:54-61). `hip_stream` is a hipStream_t. */

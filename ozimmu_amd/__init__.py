@@ -99,6 +99,8 @@ def lib():
     L.ozimmu_hip_mantissa_loss.argtypes = [vp, i, i, sz, sz, sz, vp, sz, vp, sz, C.POINTER(C.c_uint64)]
     L.ozimmu_hip_native_dgemm.restype = i
     L.ozimmu_hip_native_dgemm.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz]
+    L.ozimmu_hip_device_info.restype = i
+    L.ozimmu_hip_device_info.argtypes = [vp, C.POINTER(C.c_double)]
     L.ozimmu_hip_last_stage_ms.restype = i
     L.ozimmu_hip_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = L
@@ -180,6 +182,14 @@ def last_stage_ms(handle):
     ms = (C.c_float * 3)()
     lib().ozimmu_hip_last_stage_ms(handle.ptr, ms)
     return {"split_A": ms[0], "split_B": ms[1], "int8tc": ms[2]}
+
+
+def device_info(handle):
+    """what the launch policy plans with on the handle's device (include/ozimmu_hip.h: ozimmu_hip_device_info)"""
+    v = (C.c_double * 4)()
+    if lib().ozimmu_hip_device_info(handle.ptr, v):
+        raise RuntimeError("ozimmu_hip_device_info failed")
+    return {"cus": int(v[0]), "xcds": int(v[1]), "mfma32_us": v[2], "mfma32_measured_us": v[3]}
 
 
 def set_auto_mantissa_loss_threashold(handle, threshold):

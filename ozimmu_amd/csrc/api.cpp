@@ -199,6 +199,18 @@ static bool one_pass_split(size_t operand_bytes) {
   return operand_bytes <= config().split_one_pass_bytes;
 }
 
+// K <= 2048: ONE read of the operands, every strip of 8 / 16 / 32 rows held in the registers of one workgroup (split.hip:
+// split_resident_kernel): 8 + S bytes per element instead of 16 + S, one split launch per call instead of two, no exponent
+// words.  It pays where the split is latency- and launch-bound (1024^3 +7 % of the call, 1024 x 1024 x 2048 +3.5 %, 2048^3
+// +2.5 %, 4096 x 4096 x 1024 +1 %) and is neutral to slightly worse beyond (3072^3 ... 4096^3 -0.3 %; the 8-row strips that
+// K = 4096 needs -1.8 %): by policy up to K = 2048; OZIMMU_HIP_SPLIT_RESIDENT=8 / 16 / 32 forces it up to K = 4096 / 2048 /
+// 1024, =0 keeps the two-pass forms (the parity tests run every form).
+static bool resident_split(size_t k) {
+  const int f = config().split_resident;
+  if (f == 0 || config().split_one_pass_bytes != 0) return false;
+  return k <= (f > 0 ? resident_split_max_k() : (size_t)2048);
+}
+
 // Problems whose operands total at most this many bytes split all their operand views with ONE launch per pass
 // (row_max_kernel / cut_multi_kernel): they are bounded by launch gaps.  Larger ones keep one launch per view (each
 // layout at its own occupancy) and walk row bands.  OZIMMU_HIP_SPLIT_MULTI_BYTES overrides (0: never).
@@ -343,21 +355,41 @@ struct WorkspaceUse {
   // untouched"; the interposer then lets the vendor routine run / be captured)
   bool ok = true;
   bool capturing = false;
+  int restore_device = -1; // the caller's current device, when it is not the handle's
   explicit WorkspaceUse(ozimmu_hip_handle_t handle) : h(handle) {
+    // the workspace, the stream, the topology the launch policy plans with and every launch belong to the handle's device:
+    // make it current for the duration of the call if the caller has another one selected
+    int cur = h->device;
+    if (hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess) restore_device = cur;
     // A stream that is being captured into a graph executes nothing now: no synchronisation is legal on it (a
     // hipDeviceSynchronize under global capture mode invalidates the user's capture), and an event recorded on it becomes a
     // graph node that an eager hipStreamWaitEvent cannot wait for.  Captured calls therefore never touch the tail state.
     // A call captured on a stream OTHER than its predecessor's has no ordering against that predecessor's eager work:
     // refuse it (the common flow - eager matmuls on the default stream, then torch.cuda.graph on a side stream - then
-    // captures the vendor GEMM).  Ordering a graph REPLAY against eager calls on other streams is the caller's business,
-    // as for any library with a per-handle workspace.
+    // captures the vendor GEMM).  A graph REPLAY is ordered against later eager calls by a device synchronisation in front
+    // of them once the handle has seen a capture and more than one stream (below); two graphs replaying CONCURRENTLY on
+    // different streams share the workspace they were captured with and remain the caller's business.
     capturing = stream_is_capturing(h->stream);
+    if (!h->first_stream_known) {
+      h->first_stream = h->stream;
+      h->first_stream_known = true;
+    } else if (h->stream != h->first_stream) {
+      h->several_streams = true;
+    }
     const bool other_stream = h->tail_stream_known && h->tail_stream != h->stream && !config().test_no_stream_order;
     if (capturing) {
       ok = !other_stream;
       return;
     }
-    if (other_stream) {
+    if (h->seen_capture && h->several_streams) {
+      // A graph captured from this handle replays without the library seeing it: a replay records no tail event, and it may
+      // run on any stream.  Once a handle has been captured AND has seen more than one stream (capture streams included),
+      // the only ordering an eager call can get against a replay in flight is a device synchronisation (an
+      // application that keeps its graph replays and its eager GEMMs on ONE stream never gets here).
+      hipDeviceSynchronize();
+      (void)hipGetLastError();
+      h->multi_stream = true;
+    } else if (other_stream) {
       if (h->multi_stream && h->tail_valid) {
         hipStreamWaitEvent(h->stream, h->tail_ev, 0);
       } else {
@@ -368,6 +400,7 @@ struct WorkspaceUse {
     }
   }
   ~WorkspaceUse() {
+    if (restore_device >= 0) hipSetDevice(restore_device);
     if (capturing) return; // nothing ran; the tail stays what the last eager call left
     h->tail_valid = h->multi_stream && h->tail_ev && hipEventRecord(h->tail_ev, h->stream) == hipSuccess;
     if (h->multi_stream && !h->tail_valid) (void)hipGetLastError();
@@ -435,11 +468,19 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   const bool use_phase = wants_phase(m, n, k, bs.count);
   // the phase hints / claim counters are cleared by the first row-maximum launch on the side (kernels.h: SplitJobs::zero_ptr);
   // a call without that launch (one-pass split, row maxima left by the auto-mode statistic) clears them with a launch of its own
-  const bool zero_in_row_max = use_phase && !have_row_max && !one_pass_split(8 * (m + n) * k * bs.count);
+  const bool resident = !have_row_max && resident_split(k);
+  const bool zero_in_row_max = use_phase && !have_row_max && (resident || !one_pass_split(8 * (m + n) * k * bs.count));
   uint32_t *const zp = zero_in_row_max ? w.phase : nullptr;
   const uint32_t zw = (uint32_t)topology().xcds * PHASE_LINE_WORDS;
   if (use_phase && !zero_in_row_max && !zero_phase_lines(h, w.phase)) return 3;
-  if (one_pass_split(8 * (m + n) * k * bs.count)) {
+  if (resident) {
+    // one read, both operands (and every matrix of the batch) in one launch
+    const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, nullptr},
+                              {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, nullptr}};
+    if (!hip_ok(launch_split_resident(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot, zp, zw, topology().cus), "split"))
+      return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3; // split_A + split_B -> split_A
+  } else if (one_pass_split(8 * (m + n) * k * bs.count)) {
     // both operands (and every matrix of the batch) in one launch
     const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, nullptr},
                               {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, nullptr}};
@@ -586,8 +627,18 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
   const bool prof = h->profiling && !stream_is_capturing(h->stream); // the stage timer synchronises on its events
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
   const bool use_phase = wants_phase(m, n, k, bs.count);
-  if (use_phase && !zero_phase_lines(h, w.phase)) return 3;
-  if (one_pass_split(16 * (m + n) * k * bs.count)) {
+  const bool resident = !have_row_max && resident_split(k);
+  if (use_phase && !resident && !zero_phase_lines(h, w.phase)) return 3;
+  if (resident) {
+    const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, nullptr},
+                              {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, nullptr},
+                              {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, nullptr},
+                              {view_B_part(op_B, k, n, b, ldb, 1), w.planes_b[1], w.eb[1], bb.in_stride, nullptr}};
+    if (!hip_ok(launch_split_resident(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot, use_phase ? w.phase : nullptr,
+                                      (uint32_t)topology().xcds * PHASE_LINE_WORDS, topology().cus), "split"))
+      return 3;
+    if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
+  } else if (one_pass_split(16 * (m + n) * k * bs.count)) {
     const SplitJob jobs[4] = {{view_A_part(op_A, m, k, a, lda, 0), w.planes_a[0], w.ea[0], ba.in_stride, nullptr},
                               {view_A_part(op_A, m, k, a, lda, 1), w.planes_a[1], w.ea[1], ba.in_stride, nullptr},
                               {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, nullptr},
@@ -763,6 +814,7 @@ int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm) { //
   ozimmu_hip_handle *h = new (std::nothrow) ozimmu_hip_handle;
   if (!h) return 1;
   h->malloc_mode = mm;
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
   if (!hip_ok(hipMalloc((void **)&h->d_mantissa_loss_counter_ptr, sizeof(unsigned long long) * 16),
               "hipMalloc(counters)")) {
     delete h;
@@ -786,6 +838,20 @@ int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm) { //
   h->intercept_threshold_n = read_thr("OZIMMU_INTERCEPT_THRESHOLD_N");
   h->intercept_threshold_k = read_thr("OZIMMU_INTERCEPT_THRESHOLD_K");
   *handle = h;
+  return 0;
+}
+
+int ozimmu_hip_device_info(ozimmu_hip_handle_t h, double out[4]) {
+  if (!h || !out) return 1;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
+  int cur = h->device;
+  const bool other = hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess;
+  const Topology t = topology();
+  if (other) hipSetDevice(cur);
+  out[0] = t.cus;
+  out[1] = t.xcds;
+  out[2] = t.mfma32_us;
+  out[3] = t.mfma32_measured_us;
   return 0;
 }
 
@@ -1285,7 +1351,11 @@ int ozimmu_hip_split_int8(ozimmu_hip_handle_t h, int8_t *out_ptr, uint32_t ldo, 
   bool ok = hip_ok(hipMemsetAsync(exps, 0, exps_bytes, h->stream), "memset");
   if (v.K == 0) // nothing to cut: max_exp of an empty row is 0
     ok = ok && hip_ok(hipMemsetAsync(max_exp_ptr, 0, 8 * v.rows, h->stream), "memset");
-  if (one_pass_split(8 * v.rows * v.K)) { // the same kernel choice as the GEMM path makes for this operand size
+  if (v.K > 0 && resident_split(v.K)) { // the same kernel choice as the GEMM path makes for this K
+    const SplitJob job{v, planes, max_exp_ptr, 0, nullptr};
+    ok = ok && hip_ok(launch_split_resident(&job, 1, (int)num_split, (int)bits_per_int8, h->stream, 1, 0, nullptr, 0,
+                                            topology().cus), "split");
+  } else if (one_pass_split(8 * v.rows * v.K)) {
     const SplitJob job{v, planes, max_exp_ptr, 0, nullptr};
     ok = ok && hip_ok(launch_split_fused(&job, 1, (int)num_split, (int)bits_per_int8, h->stream), "split");
   } else {

@@ -51,6 +51,7 @@ static Config read_config() {
   c.split_multi_bytes = (size_t)number("OZIMMU_HIP_SPLIT_MULTI_BYTES", (long long)c.split_multi_bytes);
   c.batch_workspace_bytes = (size_t)number("OZIMMU_HIP_BATCH_WORKSPACE_BYTES", 0);
   c.split_strip = (int)number("OZIMMU_HIP_SPLIT_STRIP", 0);
+  c.split_resident = (int)number("OZIMMU_HIP_SPLIT_RESIDENT", -1);
 #ifdef OZIMMU_HIP_TEST_HOOKS
   c.test_fail_launch = (int)number("OZIMMU_HIP_TEST_FAIL_LAUNCH", 0);
   c.test_exp_epoch = (uint32_t)number("OZIMMU_HIP_TEST_EXP_EPOCH", 0);
@@ -59,7 +60,9 @@ static Config read_config() {
   return c;
 }
 
-const Config &config() {
+// By value: in the follow-the-environment mode of the tests the static copy is rewritten on every call, and a reference
+// handed out earlier (to another thread, or to an expression that calls config() twice) would see it change underneath.
+Config config() {
   static std::mutex mtx;
   static Config c;
   static std::atomic<bool> ready{false};
@@ -69,10 +72,11 @@ const Config &config() {
       c = read_config();
       ready.store(true, std::memory_order_release);
     }
-  } else if (c.env_per_call) { // tests / A-B tools: follow the environment (single-threaded use)
-    std::lock_guard<std::mutex> lock(mtx);
-    c = read_config();
+    return c;
   }
+  if (!c.env_per_call) return c; // production: written once, before `ready`
+  std::lock_guard<std::mutex> lock(mtx); // tests / A-B tools: follow the environment
+  c = read_config();
   return c;
 }
 

@@ -31,6 +31,7 @@ struct Config {
   size_t split_multi_bytes = (size_t)512 << 20; // OZIMMU_HIP_SPLIT_MULTI_BYTES
   size_t batch_workspace_bytes = 0;             // OZIMMU_HIP_BATCH_WORKSPACE_BYTES (0: default budget)
   int split_strip = 0;                          // OZIMMU_HIP_SPLIT_STRIP
+  int split_resident = -1;                      // OZIMMU_HIP_SPLIT_RESIDENT: 0 never, 8 / 16 / 32 force the strip height (-1: policy)
   // test hooks (tests/test_gpu_robustness.py)
   int test_fail_launch = 0;       // OZIMMU_HIP_TEST_FAIL_LAUNCH=n: the n-th slice-GEMM launch of a call is rejected
   uint32_t test_exp_epoch = 0;    // OZIMMU_HIP_TEST_EXP_EPOCH: jump the exponent-word epoch close to its wrap-around
@@ -38,7 +39,7 @@ struct Config {
   bool forced_kernel() const { return gemm_kernel != AUTO; }
 };
 
-const Config &config();
+Config config(); // a snapshot (by value: see config.cpp)
 
 // getenv calls made by this library so far (tests/test_interpose_cpu.py: an intercepted call reads the environment at most
 // three times)

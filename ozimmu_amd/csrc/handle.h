@@ -16,6 +16,7 @@
 
 struct ozimmu_hip_handle {
   hipStream_t stream = nullptr;
+  int device = 0; // the device this handle was created on: workspace, topology and every launch belong to it
 
   // grow-only device workspace (src/handle.hpp:12-13, src/handle.cu:63-93)
   void *working_memory_ptr = nullptr;
@@ -69,6 +70,9 @@ struct ozimmu_hip_handle {
   bool tail_valid = false;        // tail_ev was recorded at the end of the previous call
   bool tail_stream_known = false; // a previous call exists (tail_stream is its stream)
   bool multi_stream = false;      // this handle has seen calls on more than one stream: record an event per call
+  hipStream_t first_stream = nullptr; // the first stream any call (eager or captured) arrived on ...
+  bool first_stream_known = false;
+  bool several_streams = false;   // ... and whether any later call arrived on another one
 
   // private vendor BLAS handle for the `dgemm` mode (src/handle.hpp:8), created lazily
   void *rocblas_handle = nullptr;

@@ -133,6 +133,12 @@ hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStr
 hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch = 1,
                               size_t ws_stride = 0);
 
+// one read of the operands, strips held in registers (split.hip: split_resident_kernel): every view's K <= resident_split_max_k();
+// zero_ptr / zero_words as in launch_row_max_multi; cus: CUs of the device (strip height)
+size_t resident_split_max_k();
+hipError_t launch_split_resident(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch,
+                                 size_t ws_stride, uint32_t *zero_ptr, uint32_t zero_words, int cus);
+
 // tiled planes -> reference layout [S][rows][ldo] (test hook for ozimmu_hip_split_int8)
 hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int8_t *out, size_t ldo,
                          hipStream_t stream);

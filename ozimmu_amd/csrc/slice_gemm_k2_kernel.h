@@ -181,13 +181,18 @@ __device__ __forceinline__ void k2_tile(const SliceGemmArgs &p, char *smem) {
   __syncthreads();
   if (grp) return; // (the fused-products kernel meets group 0 again at its next barrier)
 #pragma unroll
-  for (int d = 0; d < ND; d++)
+  for (int d = 0; d < ND; d++) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const v4i o = *(const v4i *)(red + (d * 4 + q) * 1024);
 #pragma unroll
       for (int e = 0; e < 4; e++) acc[d][4 * q + e] += o[e];
     }
+    // one diagonal at a time, the sums pinned here: left alone the optimiser sinks the adds into the epilogue (next to the
+    // conversions that consume them) and keeps all 4 * ND LDS reads alive until then - 144 registers at ND = 9, 180 bytes of
+    // scratch per lane, in the build WITHOUT the dump hook only, which is the one that ships
+    asm volatile("" : "+v"(acc[d]));
+  }
 
   recombine_and_store<D0, ND, 1>(p, [&](int, int d, int r) { return acc[d][r]; }, tm * 64 + wm * 32 + (lane & 31),
                                  tn * 64 + wn * 32 + 4 * (lane >> 5));

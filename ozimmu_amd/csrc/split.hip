@@ -643,6 +643,209 @@ hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipS
   return hipGetLastError();
 }
 
+// ---- resident split: ONE read of the operand, the strip held in registers (round 4) ------------------------------------
+// The two-pass form reads every element twice (16 + S bytes per element) because the cut needs the row maximum of the WHOLE
+// row; the one-pass form above re-reads its strip from L2 with four waves.  Here a strip of R rows x K lives in the registers
+// of ONE workgroup of up to 8 waves: every wave loads up to 4 unit blocks of 1024 elements (R rows x 1024 / R k: 16 doubles =
+// 32 registers per lane and block, the same lane = (row, 16 consecutive k) assignment the cut works on), the waves combine
+// their row maxima through R words of LDS, and the cut runs on the registers.  HBM sees 8 + S bytes per element, the
+// exponent-word buffer, its epoch tags and atomics are not involved, and a call needs one split launch instead of two.
+//   R = 32: K <= 1024, unit block = one 32 x 32 fragment block;   R = 16: K <= 2048, 16 rows x 64 k;   R = 8: K <= 4096, 8 x 128.
+// The host takes the tallest strip that still gives every CU a workgroup (small problems are bound by the cut's VALU work and
+// by latency, not by bandwidth: 1024 x 1024 x 2 operands in 32-row strips would keep 64 of 256 CUs busy).
+// Loads are coalesced in both layouts: row-contiguous operands directly (R * 8 bytes per k), k-contiguous ones with the
+// lanes along k (runs of 256 bytes and more) and a transpose through the wave's LDS tile.
+template <int R, bool KCONTIG>
+__device__ __forceinline__ void fetch_unit(const double *__restrict__ in, size_t rows, size_t K, size_t sr, size_t sk,
+                                           size_t row0, size_t k0, int lane, double t[16]) {
+  constexpr int KU = 1024 / R; // k per unit block
+  if constexpr (!KCONTIG) {
+    const size_t rg = row0 + (size_t)(lane % R);
+    const size_t kbase = k0 + (size_t)(lane / R) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const size_t k = kbase + q;
+      t[q] = (rg < rows && k < K) ? in[k * sk + rg * sr] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; it++) { // instruction `it` covers elements it * 64 .. + 63 of the unit in (row, k) order
+      const int el = it * 64 + lane;
+      const size_t rg = row0 + (size_t)(el / KU), k = k0 + (size_t)(el % KU);
+      t[it] = (rg < rows && k < K) ? in[rg * sr + k * sk] : 0.0;
+    }
+  }
+}
+// k-contiguous: t[] (lanes along k) -> v[] (16 consecutive k of row lane % R) through the wave's tile [R][1024 / R + 1]
+template <int R>
+__device__ __forceinline__ void transpose_unit(const double t[16], int lane, double *tile, double v[16]) {
+  constexpr int KU = 1024 / R, LD = KU + 1;
+  __builtin_amdgcn_wave_barrier(); // the previous block's reads of the tile are done
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int it = 0; it < 16; it++) {
+    const int el = it * 64 + lane;
+    tile[(el / KU) * LD + el % KU] = t[it];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int r = lane % R, g = lane / R;
+#pragma unroll
+  for (int q = 0; q < 16; q++) v[q] = tile[r * LD + g * 16 + q];
+}
+
+constexpr int RES_MAX_WAVES = 8, RES_UNITS = 4;
+constexpr int RES_TILE_DOUBLES = 1056; // >= R * (1024 / R + 1) for R = 32, 16, 8
+
+template <int R, bool KCONTIG, bool LOW>
+__device__ __forceinline__ void split_resident_strip(const SplitJob &j, int S, int L, size_t strip, double *tile,
+                                                     unsigned *row_e) {
+  constexpr int KU = 1024 / R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const size_t rows = j.v.rows, K = j.v.K, sr = j.v.stride_r, sk = j.v.stride_k;
+  const size_t KB = k_blocks(K), NU = (KB * 32 + KU - 1) / KU; // unit blocks along k (the last one may be partial: KB * 32 % KU)
+  const size_t row0 = strip * R;
+  if (threadIdx.x < R) row_e[threadIdx.x] = 0u;
+  __syncthreads();
+  // unit block u of this wave: number wave + nwaves * u along k (neighbouring waves read neighbouring memory)
+  double v[RES_UNITS][16];
+  unsigned e = 0;
+  if (row0 < rows) {
+#pragma unroll
+    for (int u = 0; u < RES_UNITS; u++) {
+      const size_t ub = (size_t)wave + (size_t)nwaves * u;
+      if (ub < NU) {
+        if constexpr (KCONTIG) {
+          double t[16];
+          fetch_unit<R, true>(j.v.in, rows, K, sr, sk, row0, ub * KU, lane, t);
+          transpose_unit<R>(t, lane, tile, v[u]);
+        } else {
+          fetch_unit<R, false>(j.v.in, rows, K, sr, sk, row0, ub * KU, lane, v[u]);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const unsigned x = exp_field(v[u][q]);
+          e = x > e ? x : e;
+        }
+      }
+    }
+    if (e) atomicMax(&row_e[lane % R], e); // LDS
+  }
+  __syncthreads();
+  e = row_e[lane % R];
+  const size_t rg = row0 + (size_t)(lane % R);
+  if (wave == 0 && lane < R && rg < rows) j.max_exp[rg] = max_exp_of(e);
+  // rows beyond `rows` (the planes are padded to TILE_ROWS) and k beyond K were read as +0.0: e = 0 / zero slices
+  const size_t rb = row0 / 32;
+  const int g = lane / R; // k-group of 16 inside the unit: k-block g >> 1 of the unit's KU / 32, k-half g & 1
+#pragma unroll
+  for (int u = 0; u < RES_UNITS; u++) {
+    const size_t ub = (size_t)wave + (size_t)nwaves * u;
+    if (ub < NU) {
+      if (row0 >= rows) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[u][q] = 0.0;
+      }
+      const size_t kb = ub * (KU / 32) + (size_t)(g >> 1);
+      if (kb >= KB) continue; // the last unit of an operand whose KB is no multiple of KU / 32 reaches beyond the planes
+      int8_t *out = j.planes + ((rb * KB + kb) * (size_t)S) * FRAG_BYTES + (size_t)(g & 1) * 512 +
+                    (size_t)((row0 & 31) + lane % R) * 16;
+      cut_and_store<LOW>(v[u], row0 < rows ? e : 0u, S, L, out);
+    }
+  }
+}
+
+template <int R, bool LOW>
+__global__ __launch_bounds__(64 * RES_MAX_WAVES) void split_resident_kernel(const SplitJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) double res_tiles[]; // [waves][RES_TILE_DOUBLES]: k-contiguous views only
+  __shared__ unsigned row_e[32];
+  int ji = 0;
+  uint32_t strip = blockIdx.x;
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    if (ji + 1 < jobs.count && strip >= jobs.nblk[ji]) {
+      strip -= jobs.nblk[ji];
+      ji++;
+    }
+  if (jobs.zero_words && blockIdx.x == 0 && blockIdx.z == 0)
+    for (uint32_t i = threadIdx.x; i < jobs.zero_words; i += blockDim.x) jobs.zero_ptr[i] = 0u;
+  SplitJob j = jobs.job[0];
+  if (ji == 1) j = jobs.job[1];
+  if (ji == 2) j = jobs.job[2];
+  if (ji == 3) j = jobs.job[3];
+  j.v.in += (long long)blockIdx.z * j.in_stride;
+  j.planes += (size_t)blockIdx.z * jobs.ws_stride;
+  j.max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + (size_t)blockIdx.z * jobs.ws_stride);
+  double *tile = res_tiles + (size_t)(threadIdx.x >> 6) * RES_TILE_DOUBLES;
+  if (j.v.stride_k < j.v.stride_r)
+    split_resident_strip<R, true, LOW>(j, jobs.S, jobs.L, strip, tile, row_e);
+  else
+    split_resident_strip<R, false, LOW>(j, jobs.S, jobs.L, strip, tile, row_e);
+}
+
+// the longest K a resident strip (8 rows) can hold: 8 waves x 4 unit blocks x 128 k
+size_t resident_split_max_k() { return (size_t)RES_MAX_WAVES * RES_UNITS * 128; }
+
+hipError_t launch_split_resident(const SplitJob *job, int count, int S, int L, hipStream_t stream, uint32_t batch,
+                                 size_t ws_stride, uint32_t *zero_ptr, uint32_t zero_words, int cus) {
+  if (count < 1 || count > 4) return hipErrorInvalidValue;
+  SplitJobs jobs{};
+  jobs.count = count;
+  jobs.S = S;
+  jobs.L = L;
+  jobs.ws_stride = ws_stride;
+  jobs.zero_ptr = zero_ptr;
+  jobs.zero_words = zero_ptr ? zero_words : 0;
+  size_t kmax = 0, blocks32 = 0;
+  bool any_kcontig = false;
+  for (int i = 0; i < count; i++) {
+    if (job[i].v.K > resident_split_max_k()) return hipErrorInvalidValue;
+    kmax = std::max(kmax, k_blocks(job[i].v.K) * 32);
+    blocks32 += row_blocks_padded(job[i].v.rows);
+    any_kcontig = any_kcontig || job[i].v.stride_k < job[i].v.stride_r;
+  }
+  // strip height: the tallest of 32 / 16 / 8 rows whose K capacity (1024 / 2048 / 4096) covers the operands and that still
+  // gives every CU a workgroup; OZIMMU_HIP_SPLIT_RESIDENT=8 / 16 / 32 forces it where K allows
+  auto capacity = [](int r) { return (size_t)RES_MAX_WAVES * RES_UNITS * (size_t)(1024 / r); };
+  const int forced = config().split_resident;
+  int R = 32;
+  if (forced == 8 || forced == 16 || forced == 32) {
+    R = forced;
+    while (R > 8 && kmax > capacity(R)) R /= 2;
+  } else {
+    // (tools/ab.py, profiles/r4_ablate/r4f_resident_split_strip_height.txt: 1024^3 and 1024 x 1024 x 2048 want 256 strips of 8
+    // rows rather than 128 of 16: +12 / +9 % of the call; 1536^3 is better off with 192 strips of 16 than with 384 of 8)
+    while (R > 8 && (kmax > capacity(R) || 8 * blocks32 * (size_t)(32 / R) * batch < 5 * (size_t)cus)) R /= 2;
+  }
+  const size_t ku = 1024 / R;
+  const size_t nu = (kmax + ku - 1) / ku;                                  // unit blocks of the longest view
+  // waves per workgroup: <= 4 unit blocks per wave, and no wave idling through the last round of blocks (12 blocks: 6 waves x 2)
+  const size_t per_wave = (std::max<size_t>(1, nu) + RES_MAX_WAVES - 1) / RES_MAX_WAVES;
+  const unsigned waves = (unsigned)((std::max<size_t>(1, nu) + per_wave - 1) / per_wave);
+  uint64_t total = 0;
+  for (int i = 0; i < count; i++) {
+    jobs.job[i] = job[i];
+    jobs.nblk[i] = (uint32_t)(row_blocks_padded(job[i].v.rows) * (32 / R));
+    total += jobs.nblk[i];
+  }
+  if (total == 0 || batch == 0)
+    return jobs.zero_words ? launch_zero_words(zero_ptr, (size_t)zero_words * 4, 0, 1, stream) : hipSuccess;
+  if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  const size_t lds = any_kcontig ? sizeof(double) * waves * RES_TILE_DOUBLES : 0;
+  const dim3 grid((unsigned)total, 1, batch), block(64 * waves);
+  const bool low = S * L > 64; // some slice reaches into the lower 64 bits of the shifted mantissa
+#define OZ_RES_LAUNCH(RR)                                                                                        \
+  do {                                                                                                           \
+    if (low) hipLaunchKernelGGL((split_resident_kernel<RR, true>), grid, block, lds, stream, jobs);               \
+    else hipLaunchKernelGGL((split_resident_kernel<RR, false>), grid, block, lds, stream, jobs);                  \
+  } while (0)
+  if (R == 32) OZ_RES_LAUNCH(32);
+  else if (R == 16) OZ_RES_LAUNCH(16);
+  else OZ_RES_LAUNCH(8);
+#undef OZ_RES_LAUNCH
+  return hipGetLastError();
+}
+
 // ---- test hook: tiled planes -> reference layout [S][rows][ldo] --------------------------------------
 __global__ void untile_kernel(const int8_t *__restrict__ planes, size_t rows, size_t K, int S,
                               int8_t *__restrict__ out, size_t ldo, size_t KB) {

@@ -13,6 +13,7 @@ struct Topology {
   int cus = 256;
   int xcds = 8;
   double mfma32_us = 0.0194; // one 32x32x32 INT8 MFMA on one SIMD, sustained (32 cycles at ~1.65 GHz) until calibrated
+  double mfma32_measured_us = 0; // what the probe measured (mfma32_us is this value clamped to +-25 % of the nominal one)
   bool probed = false;
 };
 

@@ -79,19 +79,27 @@ void probe_topology() {
     if (hipMemset(d, 0, 256) == hipSuccess) {
       hipLaunchKernelGGL(xcc_probe_kernel, dim3(4 * t.cus), dim3(64), 0, 0, d);
       if (hipMemcpy(&h, d, 4, hipMemcpyDeviceToHost) == hipSuccess && h >= 1 && h <= 16) t.xcds = (int)h;
-      // sustained MFMA time: one untimed pass (clock ramp), one timed pass of ~1 ms
+      // sustained MFMA time: one untimed pass (clock ramp), then the FASTEST of three timed passes of ~1 ms (another tenant
+      // of the device can only make a pass slower), accepted only within +-25 % of the nominal 32 cycles at 1.65 GHz: the
+      // kernel choice must not swing with whatever else ran during this millisecond
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         const int iters = 4000; // 48 000 MFMAs per wave ~ 0.8 - 1 ms
         hipLaunchKernelGGL(mfma_calibration_kernel, dim3(t.cus), dim3(256), 0, 0, iters, (int *)d);
-        hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(mfma_calibration_kernel, dim3(t.cus), dim3(256), 0, 0, iters, (int *)d);
-        hipEventRecord(e1, 0);
-        float ms = 0;
-        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) {
-          const double us = (double)ms * 1e3 / ((double)iters * 12.0);
-          if (us > 0.005 && us < 0.2) t.mfma32_us = us; // 32 cycles at 6.4 GHz .. 160 MHz: anything else is a failed probe
+        double best = 0;
+        for (int rep = 0; rep < 3; rep++) {
+          hipEventRecord(e0, 0);
+          hipLaunchKernelGGL(mfma_calibration_kernel, dim3(t.cus), dim3(256), 0, 0, iters, (int *)d);
+          hipEventRecord(e1, 0);
+          float ms = 0;
+          if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) {
+            const double us = (double)ms * 1e3 / ((double)iters * 12.0);
+            if (best == 0 || us < best) best = us;
+          }
         }
+        t.mfma32_measured_us = best;
+        const double nominal = Topology().mfma32_us;
+        if (best > 0) t.mfma32_us = std::min(std::max(best, 0.75 * nominal), 1.25 * nominal);
       }
       if (e0) hipEventDestroy(e0);
       if (e1) hipEventDestroy(e1);

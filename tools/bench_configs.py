@@ -2,7 +2,7 @@
 per call): C3 = fp64_int8_{3..18} at 4096^3, C5 = fp64_int8_9 32768 x 32768 x 1024 N/T, 16384^3 at S = 9 / 11 (C4's mode)."""
 import os; os.environ.setdefault("OZIMMU_HIP_ENV_PER_CALL", "1")  # switches are flipped between calls (csrc/config.h)
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ozimmu_amd as oz
 h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
 def bench(m, n, k, opa, opb, mode, kernel, reps):

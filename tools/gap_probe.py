@@ -4,7 +4,7 @@ and the k64 tile function, and rocBLAS DGEMM.  (A kernel that starts on an idle 
 start-of-load transient.)"""
 import os; os.environ.setdefault("OZIMMU_HIP_ENV_PER_CALL", "1")
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ozimmu_amd as oz
 m, n, k = (int(x) for x in sys.argv[1:4]); oa, ob = sys.argv[4:6]
 h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())

@@ -1,7 +1,7 @@
 """tools/host_time.py — host time to enqueue one call (loop of 50 queued calls timed before the synchronisation) next to the
 device time per call, fp64_int8_9 and rocBLAS DGEMM: what a caller that synchronises after every call pays on top."""
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ozimmu_amd as oz
 h = oz.create(); oz.set_cuda_stream(h, torch.cuda.current_stream())
 for (m, n, k, oa, ob) in [(256, 256, 256, "N", "N"), (1024, 1024, 1024, "N", "N"), (2048, 2048, 2048, "N", "N"), (4096, 4096, 4096, "N", "N"),

@@ -3,7 +3,7 @@
 block: separates the first ~0.3 s of a run (the part's power-averaging window) from the sustained state."""
 import os; os.environ.setdefault("OZIMMU_HIP_ENV_PER_CALL", "1")
 import sys, time, subprocess, threading, re, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ozimmu_amd as oz
 m, n, k = (int(x) for x in sys.argv[1:4]); oa, ob = sys.argv[4:6]
 calls = int(sys.argv[6]) if len(sys.argv) > 6 else 60
