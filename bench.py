@@ -461,8 +461,7 @@ def main():
                     rf["l2_hit_rate"] = round(t.get("l2_hit_rate", 0), 3)
 
         if rf["kernel"] is None:
-            rf["kernel"] = ("slice GEMM kernel of this workload (name not captured: rocprofv3 pass skipped); fp64_int8_9 at 8192^3: "
-                            "slice_gemm_w_kernel, k64 tile function")
+            rf["kernel"] = f"(rocprofv3 pass skipped) the library reports: {oz.last_kernel(h)}"
         if not args.no_extra:
             from tools.residual import sampled_relative_residual  # numpy long double; independent of oracle/
             extra = {}
@@ -545,6 +544,22 @@ def main():
                     sizes[str(n_)] = {k_: v_["tflops"] for k_, v_ in r_.items()}
                     sizes[str(n_)]["ratio"] = round(r_["fp64_int8_9"]["tflops"] / r_["rocblas_dgemm"]["tflops"], 3)
                 extra["square_sizes_tflops"] = sizes
+            # what the launch policy ran for the headline call, what it knows about the device, and how much time its choices
+            # lose against the best forced kernel on a handful of other shapes (tools/ab.py: the A/B harness; the full sweep:
+            # profiles/r4_policy/)
+            step()
+            torch.cuda.synchronize()
+            extra["kernel_of_the_timed_call"] = oz.last_kernel(h)
+            extra["device_info"] = oz.device_info(h)
+            try:  # (a child process: forcing kernels needs the library's follow-the-environment mode, which this process,
+                  #  whose timings are the product's, does not run in)
+                import subprocess
+                out_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab.py"), "--preset", "bench", "--regret-json"],
+                                      capture_output=True, text=True, timeout=180, cwd=ROOT)
+                line = [l for l in out_.stdout.splitlines() if l.startswith("{")]
+                extra["policy_regret"] = json.loads(line[-1]) if line else {"error": (out_.stderr or out_.stdout)[-300:]}
+            except Exception as e:
+                extra["policy_regret"] = {"error": repr(e)}
             clk = clocks_under_load(1.5, step, torch.cuda.synchronize)
             if clk:
                 extra["clock_under_load"] = clk

@@ -95,6 +95,19 @@ int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm);
  * policy plans with (the measured value clamped to +-25 % of the nominal 0.0194), out[3] = the measured value itself.  No
  * counterpart in the reference (it has no kernel choice: src/gemm.cu:315-329 calls cuBLAS). */
 int ozimmu_hip_device_info(ozimmu_hip_handle_t handle, double out[4]);
+/* Diagnostics of the kernel choice (csrc/kernel_policy.h; the reference has none: src/gemm.cu:315-329 calls cuBLAS per pair).
+ * ozimmu_hip_policy_predict: the cost model's predicted GEMM-stage time in us of every kernel for pass `pass` (0: the single
+ *   / first diagonal pass, 1: the second pass of fp64_int8_13..18) of an m x n x k product (its first K chunk) at `num_split`
+ *   slices: out_us[0..5] = K-split, classic, wide 32x32x32, wide paired 16x16x64, wide k64 (B through LDS), wide k64 (B in
+ *   registers); < 0 = not eligible.  *pick = index of the kernel the policy takes (k64 in registers: 4 + 8).  handle may be
+ *   NULL: the prediction is then made for the nominal device (256 CUs) - host arithmetic only, no GPU needed.
+ * ozimmu_hip_policy_params: read (set = 0) / replace (set = 1) the first `count` fitted constants of the model.
+ * ozimmu_hip_last_kernel: out[0], out[1] = the pick (as above) of the last slice-GEMM launch of this handle for its first /
+ *   second pass; -1 = none. */
+int ozimmu_hip_policy_predict(ozimmu_hip_handle_t handle, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
+                              double out_us[6], int *pick);
+int ozimmu_hip_policy_params(double *params, int count, int set);
+int ozimmu_hip_last_kernel(ozimmu_hip_handle_t handle, int out[2]);
 int ozimmu_hip_destroy(ozimmu_hip_handle_t handle);
 
 /* ozimmu.hpp:50-51 set_cuda_stream (src/handle.cu:54-61). `hip_stream` is a hipStream_t. */

@@ -101,6 +101,12 @@ def lib():
     L.ozimmu_hip_native_dgemm.argtypes = [vp, i, i, sz, sz, sz, vp, vp, sz, vp, sz, vp, vp, sz]
     L.ozimmu_hip_device_info.restype = i
     L.ozimmu_hip_device_info.argtypes = [vp, C.POINTER(C.c_double)]
+    L.ozimmu_hip_policy_predict.restype = i
+    L.ozimmu_hip_policy_predict.argtypes = [vp, i, i, sz, sz, sz, sz, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.ozimmu_hip_policy_params.restype = i
+    L.ozimmu_hip_policy_params.argtypes = [C.POINTER(C.c_double), i, i]
+    L.ozimmu_hip_last_kernel.restype = i
+    L.ozimmu_hip_last_kernel.argtypes = [vp, C.POINTER(C.c_int)]
     L.ozimmu_hip_last_stage_ms.restype = i
     L.ozimmu_hip_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = L
@@ -190,6 +196,41 @@ def device_info(handle):
     if lib().ozimmu_hip_device_info(handle.ptr, v):
         raise RuntimeError("ozimmu_hip_device_info failed")
     return {"cus": int(v[0]), "xcds": int(v[1]), "mfma32_us": v[2], "mfma32_measured_us": v[3]}
+
+
+KERNEL_NAMES = {0: "k2", 1: "classic", 2: "wide", 3: "x16", 4: "k64", 12: "k64_breg", -1: None}
+POLICY_PARAMS = 40
+
+
+def policy_predict(handle, num_split, m, n, k, batch=1, pass_index=0):
+    """the cost model's prediction (us) per kernel and the policy's pick (include/ozimmu_hip.h: ozimmu_hip_policy_predict)"""
+    out = (C.c_double * 6)()
+    pick = C.c_int(-1)
+    if lib().ozimmu_hip_policy_predict(handle.ptr if handle is not None else None, num_split, pass_index, m, n, k, batch, out,
+                                       C.byref(pick)):
+        raise RuntimeError("ozimmu_hip_policy_predict failed")
+    names = ["k2", "classic", "wide", "x16", "k64", "k64_breg"]
+    return {nm: out[j] for j, nm in enumerate(names) if out[j] >= 0}, KERNEL_NAMES.get(pick.value, str(pick.value))
+
+
+def policy_params(new=None):
+    """read (new=None) or replace the fitted constants of the kernel-choice model"""
+    v = (C.c_double * POLICY_PARAMS)()
+    if new is not None:
+        for j, x in enumerate(new):
+            v[j] = float(x)
+        if lib().ozimmu_hip_policy_params(v, len(new), 1):
+            raise RuntimeError("ozimmu_hip_policy_params failed")
+        return list(new)
+    lib().ozimmu_hip_policy_params(v, POLICY_PARAMS, 0)
+    return list(v)
+
+
+def last_kernel(handle):
+    """names of the kernels the last slice-GEMM launch of this handle ran (first / second diagonal pass)"""
+    v = (C.c_int * 2)()
+    lib().ozimmu_hip_last_kernel(handle.ptr, v)
+    return [KERNEL_NAMES.get(v[0], str(v[0])), KERNEL_NAMES.get(v[1], str(v[1]))]
 
 
 def set_auto_mantissa_loss_threashold(handle, threshold):

@@ -18,6 +18,7 @@
 
 #include "config.h"
 #include "handle.h"
+#include "kernel_policy.h"
 #include "kernels.h"
 #include "layout.h"
 #include "tile_plan.h"
@@ -136,7 +137,7 @@ static bool hip_ok(hipError_t e, const char *what) {
 // Test hook (tests/test_gpu_robustness.py): OZIMMU_HIP_TEST_FAIL_LAUNCH=n makes the n-th slice-GEMM launch of a call fail
 // the way a rejected launch does, so that the error paths (C untouched -> vendor fallback; C already modified -> error
 // status, no fallback) can be exercised without breaking the device.
-static bool launch_gemm_checked(int S, const SliceGemmArgs &g, hipStream_t stream, int &launch_index) {
+static bool launch_gemm_checked(ozimmu_hip_handle_t h, int S, const SliceGemmArgs &g, hipStream_t stream, int &launch_index) {
   launch_index++;
 #ifdef OZIMMU_HIP_TEST_HOOKS
   if (config().test_fail_launch == launch_index) {
@@ -144,7 +145,12 @@ static bool launch_gemm_checked(int S, const SliceGemmArgs &g, hipStream_t strea
     return false;
   }
 #endif
-  return hip_ok(launch_slice_gemm(S, g, stream), "slice_gemm");
+  note_pick(0, -1);
+  note_pick(1, -1);
+  const bool ok = hip_ok(launch_slice_gemm(S, g, stream), "slice_gemm");
+  h->last_kernel[0] = last_pick(0); // diagnostics (ozimmu_hip_last_kernel): what the policy launched for this handle
+  h->last_kernel[1] = last_pick(1);
+  return ok;
 }
 
 // src/utils.hpp:143-168
@@ -538,7 +544,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
     g.qslot = 2u * (uint32_t)launches; // per-launch claim counters of the wide kernel (two per K chunk: S > 12)
     // C is written by the final launch(es) only (earlier passes go to the FP64 workspace); S > 12 splits the final
     // pass into two launches of which only the second writes C: a failed launch leaves C untouched
-    if (!launch_gemm_checked(S, g, h->stream, launches)) return 3;
+    if (!launch_gemm_checked(h, S, g, h->stream, launches)) return 3;
   }
   if (prof) {
     if (!hip_ok(hipEventRecord(h->ev[3], h->stream), "event")) return 3;
@@ -724,8 +730,11 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
       g.acc_in = 0;
       g.final = 1;
     }
+    note_pick(0, -1);
     const hipError_t fe = launch_slice_gemm_fused(S, prod, 4, h->stream);
     if (fe == hipSuccess) {
+      h->last_kernel[0] = last_pick(0);
+      h->last_kernel[1] = -1;
       fused = true;
       launches = 4;
     } else if (fe != hipErrorNotSupported) {
@@ -743,7 +752,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
       g.acc_in = kb0 != 0;
       g.final = g.kb1 == g.KB;
       g.qslot = 2u * (uint32_t)launches;
-      if (!launch_gemm_checked(S, g, h->stream, launches)) return 4;
+      if (!launch_gemm_checked(h, S, g, h->stream, launches)) return 4;
     }
   }
   if (prof) {
@@ -852,6 +861,55 @@ int ozimmu_hip_device_info(ozimmu_hip_handle_t h, double out[4]) {
   out[1] = t.xcds;
   out[2] = t.mfma32_us;
   out[3] = t.mfma32_measured_us;
+  return 0;
+}
+
+int ozimmu_hip_policy_predict(ozimmu_hip_handle_t h, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
+                              double out_us[6], int *pick) {
+  if (!out_us || num_split < 3 || num_split > 18 || m == 0 || n == 0 || m >= ((size_t)1 << 31) || n >= ((size_t)1 << 31))
+    return 1;
+  const int L = bits_for_k(k);
+  PassTraits t;
+  if (L == 0 || !slice_gemm_traits(num_split, pass, &t)) return 1;
+  Topology topo; // no handle (tools/policy_fit.py on a box without a GPU): the nominal device, or what the caller put into the
+                 // last two entries of the parameter table (CUs, MFMA time of the device the measurements came from)
+  if (h) {
+    std::lock_guard<std::recursive_mutex> lock(h->mtx);
+    int cur = h->device;
+    const bool other = hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess;
+    topo = topology();
+    if (other) hipSetDevice(cur);
+  } else {
+    const double *p = policy_params();
+    if (p[POLICY_PARAMS - 2] > 0) topo.cus = (int)p[POLICY_PARAMS - 2];
+    if (p[POLICY_PARAMS - 1] > 0) topo.mfma32_us = p[POLICY_PARAMS - 1];
+  }
+  PolicyInput in;
+  in.M = (uint32_t)m;
+  in.N = (uint32_t)n;
+  in.nkb = std::min<uint32_t>((uint32_t)k_blocks(k), kb_per_pass(num_split, L)); // the first K chunk
+  in.batch = (uint32_t)std::max<size_t>(1, batch);
+  const Prediction r = policy_predict(t, in, topo, config());
+  for (int i = 0; i < POLICY_KERNELS; i++) out_us[i] = r.us[i];
+  if (pick) *pick = (int)r.pick + (r.breg ? 8 : 0);
+  return 0;
+}
+
+int ozimmu_hip_policy_params(double *params, int count, int set) {
+  if (!params || count < 0 || count > POLICY_PARAMS) return 1;
+  double *p = policy_params();
+  for (int i = 0; i < count; i++) {
+    if (set) p[i] = params[i];
+    else params[i] = p[i];
+  }
+  return 0;
+}
+
+int ozimmu_hip_last_kernel(ozimmu_hip_handle_t h, int out[2]) {
+  if (!h || !out) return 1;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
+  out[0] = h->last_kernel[0];
+  out[1] = h->last_kernel[1];
   return 0;
 }
 

@@ -6,6 +6,10 @@
 #include <cstring>
 #include <mutex>
 
+#include <cstdint>
+
+extern char **environ;
+
 namespace ozhip {
 
 static std::atomic<unsigned long long> g_getenv_calls{0};
@@ -75,8 +79,18 @@ Config config() {
     return c;
   }
   if (!c.env_per_call) return c; // production: written once, before `ready`
-  std::lock_guard<std::mutex> lock(mtx); // tests / A-B tools: follow the environment
-  c = read_config();
+  // tests / A-B tools: follow the environment - re-read only when it changed.  setenv / unsetenv replace or move entries of
+  // `environ`, so the pointers themselves are a fingerprint (~100 ns per call instead of 36 getenv calls x the dozen uses of
+  // config() per GEMM, which made the HOST the bottleneck of every sub-50-us problem the A/B tools timed).
+  std::lock_guard<std::mutex> lock(mtx);
+  static unsigned long long seen = 0;
+  unsigned long long fp = 1469598103934665603ull;
+  for (char **e = environ; e && *e; e++) fp = (fp ^ (unsigned long long)(uintptr_t)*e) * 1099511628211ull;
+  if (fp != seen) {
+    c = read_config();
+    c.env_per_call = true;
+    seen = fp;
+  }
   return c;
 }
 

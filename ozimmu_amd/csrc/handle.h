@@ -74,6 +74,10 @@ struct ozimmu_hip_handle {
   bool first_stream_known = false;
   bool several_streams = false;   // ... and whether any later call arrived on another one
 
+  // diagnostics: the kernel (kernel_policy.h: Pick, + 8 = k64 with B in registers) the last slice-GEMM launch of this handle
+  // ran for its first / second diagonal pass (-1: none)
+  int last_kernel[2] = {-1, -1};
+
   // private vendor BLAS handle for the `dgemm` mode (src/handle.hpp:8), created lazily
   void *rocblas_handle = nullptr;
 

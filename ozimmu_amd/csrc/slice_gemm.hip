@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include "config.h"
+#include "kernel_policy.h"
 #include "kernels.h"
 #include "topology.h"
 
@@ -77,6 +78,26 @@ hipError_t launch_slice_gemm_s17_17(int S, const SliceGemmArgs &a, hipStream_t s
 hipError_t launch_slice_gemm_fused_s17_17(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
 hipError_t launch_slice_gemm_s18_18(int S, const SliceGemmArgs &a, hipStream_t stream);
 hipError_t launch_slice_gemm_fused_s18_18(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+
+bool slice_gemm_traits_s3_6(int S, int pass, PassTraits *out);
+bool slice_gemm_traits_s7_10(int S, int pass, PassTraits *out);
+bool slice_gemm_traits_s11_13(int S, int pass, PassTraits *out);
+bool slice_gemm_traits_s14_15(int S, int pass, PassTraits *out);
+bool slice_gemm_traits_s16_16(int S, int pass, PassTraits *out);
+bool slice_gemm_traits_s17_17(int S, int pass, PassTraits *out);
+bool slice_gemm_traits_s18_18(int S, int pass, PassTraits *out);
+
+// what the passes of mode S can run on (kernel_policy.h); pass 0: the single / first pass, 1: the second pass of S > 12
+bool slice_gemm_traits(int S, int pass, PassTraits *out) {
+  if (S >= 3 && S <= 6) return slice_gemm_traits_s3_6(S, pass, out);
+  if (S >= 7 && S <= 10) return slice_gemm_traits_s7_10(S, pass, out);
+  if (S >= 11 && S <= 13) return slice_gemm_traits_s11_13(S, pass, out);
+  if (S >= 14 && S <= 15) return slice_gemm_traits_s14_15(S, pass, out);
+  if (S == 16) return slice_gemm_traits_s16_16(S, pass, out);
+  if (S == 17) return slice_gemm_traits_s17_17(S, pass, out);
+  if (S == 18) return slice_gemm_traits_s18_18(S, pass, out);
+  return false;
+}
 
 hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g_in, int count, hipStream_t stream) {
   if (count < 1 || count > 4) return hipErrorNotSupported;

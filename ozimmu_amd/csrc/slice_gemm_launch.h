@@ -11,6 +11,7 @@
 #include "config.h"
 #include "topology.h"
 #include "tile_plan.h"
+#include "kernel_policy.h"
 #include "slice_gemm_k2_kernel.h"
 #include "slice_gemm_w_kernel.h"
 
@@ -98,16 +99,8 @@ static hipError_t launch_k2_fused(const SliceGemmArgs *g, int count, hipStream_t
 // NA: 2 A buffers = prefetch distance 1.  Distance 2 (3 buffers) is never faster and up to 6 % slower (profiles/
 // r2_ablate: 17.66 vs 18.74 ms on the slowest box, equal on the fastest): a k-step of this kernel lasts ~2.8 us, enough
 // for a copy to land, and prefetching two steps ahead widens the k window the XCD's workgroups keep alive in L2.
-// The paired 16x16x64 tile function (slice_gemm_x_tile.h) against the 32x32x32 one on real slices of U[-1,1) data
-// (profiles/r3_ablate/r3d_paired_tile_real_data_ab.txt): it runs the part at a 15 % higher clock (less energy per MAC) but
-// needs 11 % more matrix-pipe slots (the unpaired product of every even diagonal) and 1.8x the LDS fragment reads:
-// 8192^3 S = 4..9: 3-9 % slower, S = 10..11: equal, S = 12: +2-4 %, S = 13 (second pass, 13 staged slices): +2.6 %.
-// OZIMMU_HIP_PAIRED_TILE=1 / 0 forces it on (wherever it exists) / off.
-static bool paired_tile_default(int staged_slices) {
-  if (config().paired_tile >= 0) return config().paired_tile == 1;
-  return staged_slices >= 12;
-}
-
+// (Which tile function runs where - 32x32x32, paired 16x16x64, k64 with B through LDS or in registers - is decided by the cost
+// model of kernel_policy.cpp from the measured times of all of them.)
 template <int S, int D0, int ND>
 struct WideCfg {
   static constexpr int SL = (D0 + ND < S) ? (D0 + ND) : S;
@@ -129,19 +122,6 @@ struct WideCfg {
   static constexpr int NA = 2;
   static constexpr bool ok = WA >= 1;
 };
-
-// The wide kernel wins once its tiles occupy about 3/4 of the CUs (measured, fp64_int8_9 square sizes, tools/
-// bench_kernel_choice.py: 1536^3 = 192 tiles: 177 vs 211 us; 2048^3 339 vs 347; 3072^3 1006 vs 1124; 8192^3 16.9 vs
-// 19.5 ms; at 1024^3 its 128 tiles of 64x128 lose to the classic kernel's 256 of 64x64: 92 vs 76 us).
-// OZIMMU_HIP_GEMM_KERNEL=wide|classic overrides (A/B measurements, parity tests of both kernels on small shapes).
-// With 8 or more staged slices the classic kernel's 64x64 tiles stage so much per MFMA that the wide kernel already wins
-// on ~40 % of the CUs (tools/sweep_policy.py, 1152^3: S = 9 77 vs 85 us, but S = 6 64 vs 53 us).
-static bool prefer_wide(const WidePlan &pl, uint32_t tn, int ncu, int staged_slices) {
-  if (config().gemm_kernel == Config::WIDE || config().gemm_kernel == Config::X16 || config().gemm_kernel == Config::K64) return true;
-  if (config().gemm_kernel == Config::CLASSIC) return false;
-  const uint64_t wgs = (uint64_t)(pl.n_big + pl.n_small) * tn;
-  return 10 * wgs >= (staged_slices >= 8 ? 4u : 7u) * (uint64_t)ncu;
-}
 
 // Paired tile (slice_gemm_x_tile.h): the same (32*WA) x 128 tile computed with v_mfma_i32_16x16x64_i8, two slice products
 // of a diagonal per instruction.  Registers: the same 16*WA*ND accumulator registers, 2*NQ B pair fragments, the A ring.
@@ -212,25 +192,8 @@ struct K64Cfg {
   static constexpr bool breg_ok = S <= 9 && WA == BREG_WA && BREG_WA * S * 16 + 16 * S + 4 * 4 + 4 + 24 <= 512;
   static constexpr size_t BREG_LDS = (size_t)(2 * BREG_WA) * (2 * S) * FRAG_BYTES;
 };
-// B global -> VGPR: the step has ONE form (every step prefetches; the last one wraps around), two steps per loop iteration:
-// passes with an even number of 64-k steps.  Measured at 8192^3, S = 9 (profiles/r4_ablate/): see DESIGN.md 4.2.
-template <int ND>
-static bool k64_breg(const SliceGemmArgs &a) {
-  if constexpr (!K64Cfg<ND>::breg_ok) {
-    return false;
-  } else {
-    if (((a.kb1 - a.kb0) & 3u) != 0) return false;
-    if (config().k64_breg >= 0) return config().k64_breg == 1;
-    return true;
-  }
-}
-// Measured against the 32x32x32 tile function on real slices of U[-1,1) data (profiles/r3_ablate/r3v_k64_tile_real_data_ab.txt):
-// 8192^3 S = 5 / 6 / 7 / 8 / 9 / 10: -13 / -10 / -7.5 / -10 / -7.5 / -9 % time (S = 9: 66.9 -> 72.3 TFLOP/s), 4096^3 S = 6 / 8 / 9:
-// -13 / -12 / -9 %, 2048^3 S = 9: -3 %.  The default wherever it exists; OZIMMU_HIP_K64_TILE=1 / 0 forces it on / off.
-static bool k64_tile_default(int S) {
-  if (config().k64_tile >= 0) return config().k64_tile == 1;
-  return S >= 4;
-}
+// (B global -> VGPR: the step has ONE form - every step prefetches, the last one wraps around - and the loop body holds two
+// steps: passes with k-blocks = 0 mod 4; kernel_policy.cpp offers the form only there.)
 
 template <int S, int ND, int WA, int VARW, int DMAE, int TAIL>
 static hipError_t launch_wide_kernel(const SliceGemmArgs &a0, const WidePlan &pl, size_t lds, hipStream_t stream) {
@@ -243,10 +206,10 @@ static hipError_t launch_wide_kernel(const SliceGemmArgs &a0, const WidePlan &pl
   return hipGetLastError();
 }
 template <int S, int ND>
-static hipError_t launch_wide_k64(const SliceGemmArgs &a, const WidePlan &pl, hipStream_t stream) {
+static hipError_t launch_wide_k64(const SliceGemmArgs &a, const WidePlan &pl, bool breg, hipStream_t stream) {
   using C = K64Cfg<ND>;
   if constexpr (C::breg_ok) {
-    if (k64_breg<ND>(a))
+    if (breg && ((a.kb1 - a.kb0) & 3u) == 0)
       return launch_wide_kernel<S, ND, C::BREG_WA, VARW_K64 | VARW_BREG, C::DMAE, C::TAIL>(a, pl, C::BREG_LDS, stream);
   }
   return launch_wide_kernel<S, ND, C::WA, VARW_K64 | (C::NB == 1 ? VARW_B1 : 0), C::DMAE, C::TAIL>(a, pl, C::LDS, stream);
@@ -291,10 +254,10 @@ static hipError_t launch_wide_multi_impl(const SliceGemmArgs *g, int count, cons
   return hipGetLastError();
 }
 template <int S, bool BREG = false>
-static hipError_t launch_wide_multi_k64(const SliceGemmArgs *g, int count, const WidePlan &pl, hipStream_t stream) {
+static hipError_t launch_wide_multi_k64(const SliceGemmArgs *g, int count, const WidePlan &pl, bool breg, hipStream_t stream) {
   using C = K64Cfg<S>;
   if constexpr (C::breg_ok && !BREG) {
-    if (k64_breg<S>(g[0])) return launch_wide_multi_k64<S, true>(g, count, pl, stream);
+    if (breg && ((g[0].kb1 - g[0].kb0) & 3u) == 0) return launch_wide_multi_k64<S, true>(g, count, pl, true, stream);
   }
   constexpr int WAK = BREG ? C::BREG_WA : C::WA;
   constexpr size_t LDSK = BREG ? C::BREG_LDS : C::LDS;
@@ -320,124 +283,62 @@ static hipError_t launch_wide_multi(const SliceGemmArgs *g, int count, const Wid
   return launch_wide_multi_impl<S, false>(g, count, pl, stream);
 }
 
-enum class Pick { K2, WIDE, WIDE_X16, WIDE_K64, CLASSIC };
-
-// kernel choice for one pass over the diagonals [D0, D0 + ND): the K-split kernel for at most one 64x64 tile per CU, the
-// wide kernel (32x32x32 or paired 16x16x64 tile function) when it fits the registers / LDS and the problem fills the chip,
-// else the classic one.  `pl`: the wide kernel's tile plan (valid for WIDE / WIDE_X16).
+// what the pass <S, D0, ND> can run on (kernel_policy.h), from the configuration structs above
 template <int S, int D0, int ND>
-static Pick pick_kernel(const SliceGemmArgs &a, WidePlan &pl) {
-  // S = 3: few MFMAs per staged byte even on 128x128 tiles; the classic 8-wave 128x64 kernel measures faster (4096^3,
-  // profiles/r2_sweeps: 263 vs 245 TFLOP/s); from S = 4 on the wide kernel leads (193 vs 179, then by 8-20 %)
-  constexpr bool wide_pays = ND >= 4 || D0 > 0;
-  if constexpr (K2Cfg<S, D0, ND>::ok) {
-    // no more 64x64 tiles than CUs (all matrices of a batch together): the classic kernel would run one wave per SIMD;
-    // split K inside an 8-wave workgroup instead (slice_gemm_k2_kernel.h; 1024^3 S=9: 48.6 -> see DESIGN.md)
-    const uint64_t wgs = (uint64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.batch > 1 ? a.batch : 1);
-    if constexpr (D0 == 0 && ND == S && K64Cfg<S>::ok && K64Cfg<S>::WA == 2) {
-      // ... unless 32 x 128 tiles of the k64 tile function (16x16x64, one wave per SIMD) fill at least half of the CUs once:
-      // 1024^3 at S = 9: 256 tiles, 56.4 vs 61.1 us per call (tools/ab_small_k64.py; 768^3: equal).  S = 9, 10 only: with fewer
-      // slices the k64 tile is 96+ rows high and the K-split kernel keeps a wide lead at these sizes (S = 6: +55 % time).
-      const uint64_t t32 = (uint64_t)((a.M + 31) / 32) * ((a.N + 127) / 128);
-      if (!config().forced_kernel() && config().k64_tile != 0 && a.batch <= 1 && wgs <= (uint64_t)cu_count() &&
-          ((a.kb1 - a.kb0) & 1u) == 0 && a.kb1 - a.kb0 >= 8 && t32 <= (uint64_t)cu_count() && 2 * t32 >= (uint64_t)cu_count()) {
-        pl = plan_wide(a.M, a.N, K64Cfg<S>::WA, cu_count());
-        if (pl.n_big == 0) return Pick::WIDE_K64; // the plan is one round of reduced-height tiles
-      }
-    }
-    if (config().forced_kernel() ? config().gemm_kernel == Config::K2 : (wgs <= (uint64_t)cu_count() && a.kb1 - a.kb0 >= 4))
-      return Pick::K2;
+static constexpr PassTraits pass_traits() {
+  PassTraits t{};
+  t.S = S;
+  t.D0 = D0;
+  t.ND = ND;
+  t.SL = (D0 + ND < S) ? (D0 + ND) : S;
+  int c = 0;
+  for (int i = 0; i < S; i++)
+    for (int j = 0; j < S; j++) c += (i + j >= D0 && i + j < D0 + ND && i + j <= S - 1) ? 1 : 0;
+  t.pairs = c;
+  t.k2_ok = K2Cfg<S, D0, ND>::ok;
+  t.wide_ok = WideCfg<S, D0, ND>::ok;
+  t.wide_wa = WideCfg<S, D0, ND>::WA;
+  t.x16_ok = WideCfg<S, D0, ND>::ok && PairedCfg<S, D0, ND>::ok;
+  if constexpr (D0 == 0) {
+    t.k64_ok = K64Cfg<ND>::ok;
+    t.k64_wa = K64Cfg<ND>::WA;
+    t.k64_breg_ok = K64Cfg<ND>::breg_ok;
   }
-  const bool forced = config().forced_kernel();
-  // the wide kernel keeps the k position of a pass in a 32-bit byte offset (slice_gemm_w_kernel.h: voff): a pass must stay
-  // below 2^32 bytes per row-block (unreachable with planes that fit in HBM today; enforced, not assumed)
-  const bool voff_ok = (uint64_t)(a.kb1 - a.kb0) * (uint64_t)(S * FRAG_BYTES) < (1ull << 32);
-  if (WideCfg<S, D0, ND>::ok && voff_ok && (wide_pays || forced)) {
-    const int ncu = cu_count();
-    // a strided batch fills the chip with all its matrices: plan one matrix on the CUs it gets on average
-    const uint32_t nbatch = a.batch > 1 ? a.batch : 1;
-    const int ncu_eff = (int)(ncu / nbatch) > 0 ? (int)(ncu / nbatch) : 1;
-    pl = plan_wide(a.M, a.N, WideCfg<S, D0, ND>::WA, ncu_eff);
-    // Two cases where the classic kernel's small tiles win although the wide tiles would fill the chip (tools/
-    // sweep_policy_random.py: losses of 15-50 % without these rules):
-    //  * a short k loop: a wide tile pays its claim / prologue / epilogue per tile whatever K is, against a k loop of
-    //    nk x (WA x pairs) MFMAs x the device's sustained MFMA time (topology.h: calibrated at handle creation; 19.4 ns =
-    //    32 cycles at ~1.65 GHz on a 1.4 kW MI355X); below ~12 us of loop (15 us with 11+ staged slices: K = 128 at S >= 7; 11 us with up to 5 slices:
-    //    K <= 384 at S = 4; 6 us at S = 6: nothing) the two-workgroups-per-CU kernel hides its tile boundaries better
-    //    (tools/ab_short_k_kernels.py, round 3: S = 4..10 x 12 shapes; the bar of 40 us of round 2 cost 12-19 % at
-    //    K = 256..512 with S = 6 and 5-10 % with S = 9 against this round's tile functions);
-    //  * few diagonals and a tile count that quantises badly (e.g. 300 tiles of 128x128 on 256 CUs): with S < 8 the
-    //    wide kernel's margin per block is too small to pay for a half-empty last round.
-    constexpr int PAIRS = []() {
-      int c = 0;
-      for (int i = 0; i < S; i++)
-        for (int j = 0; j < S; j++) c += (i + j >= D0 && i + j < D0 + ND && i + j <= S - 1) ? 1 : 0;
-      return c;
-    }();
-    const double loop_us = (double)(a.kb1 - a.kb0) * (WideCfg<S, D0, ND>::WA * PAIRS) * topology().mfma32_us;
-    // With up to 5 slices the wide kernel leads by 6-8 % only when its tiles fill the chip evenly (4096^3: 184 vs 169
-    // TFLOP/s at S = 4; 3163 x 1515 x 8192: 621 vs 575 us the other way).  The second pass of S >= 13 stages 11+ slices:
-    // there the classic kernel is down to one 8-wave workgroup per CU and loses at any size and K.
-    constexpr int SL = WideCfg<S, D0, ND>::SL;
-    constexpr bool second_pass = D0 > 0 && SL >= 11;
-    // ... and with fewer than four rounds of wide tiles the bar is 24 us (16 us up to 5 slices): nothing amortises a tile's
-    // boundaries then, and the classic kernel's 64x64 tiles balance ragged outputs better (tools/sweep_policy_random.py 23:
-    // 2296 x 1168 x 256 at S = 6 +28 % time on wide tiles, 1976 x 4684 x 256 at S = 9 +11 %, 4504 x 2617 x 512 at S = 4 +20 %)
-    const bool few_rounds = (uint64_t)(pl.n_big + pl.n_small) * ((a.N + 127) / 128) < 4ull * (uint64_t)ncu_eff;
-    const double bar_us = few_rounds ? (SL <= 5 ? 16.0 : 24.0) : (SL <= 5 ? 11.0 : SL == 6 ? 6.0 : SL >= 11 ? 15.0 : 12.0);
-    const bool classic_wins = !forced && !second_pass &&
-                              (loop_us < bar_us ||
-                               (SL < 8 && pl.efficiency < (SL <= 5 ? 0.9 : 0.62)));
-    if (!classic_wins && ((second_pass && !forced) || prefer_wide(pl, (a.N + 127) / 128, ncu_eff, SL))) {
-      if constexpr (D0 == 0 && K64Cfg<ND>::ok) { // single pass, or the first pass of S >= 13 (diagonals 0 .. ND-1)
-        // the k64 tile needs an even number of k-blocks in the pass (a step is two of them)
-        // ... and at least 8 of them (12 with 9+ slices): below that the larger tile of the 32x32x32 function has fewer tile
-        // boundaries per MAC (K = 128: +1...4 % time with k64 at S = 6..8; S = 9, K = 256: +2...10 %, K = 384 equal)
-        const bool long_enough = a.kb1 - a.kb0 >= (ND >= 9 ? 12u : 8u) || config().k64_tile > 0;
-        if (((a.kb1 - a.kb0) & 1u) == 0 &&
-            (forced ? config().gemm_kernel == Config::K64 : (k64_tile_default(ND) && long_enough))) {
-          const WidePlan plk = plan_wide(a.M, a.N, K64Cfg<ND>::WA, ncu_eff);
-          // Where the larger 32x32x32 tile keeps the lead (tools/ab_k64_shapes.py, tools/ab_small_rows.py, fp64_int8_9):
-          //  * its tiles fit in ONE round and the k64 tiles do not (1536^3: 192 tiles of 96x128 against 252 of 64x128 + 72 of
-          //    32x128: +6 % time with k64 although the model below says -6 %: a quarter of the CUs idles through that single
-          //    round and the power-limited part clocks the others higher);
-          //  * its plan has the smaller makespan, a block of the k64 tile costing ~0.92 of a 32x32x32 one.  Plans with
-          //    reduced tiles in them compete like any other (2560^3 / 3072^3 / 3328^3 / 3584^3 / 5120^3: -9 / -6 / -11 / -13 /
-          //    -7 % time with k64 although every one of those plans has 32-row tiles; at 3072^3 the model's 9.36 block
-          //    units for 36 + 24 rows are the 9.34 measured; S = 7: -10...-12 %).
-          // (Short K under very large outputs is no exception: 32768^2 x 1024 -7.8 % time with k64, 16384^2 x 512 -2.9 %; an
-          // earlier measurement that said otherwise timed 12 ms of host-side planning per call - tile_plan.h.)
-          const bool by_policy = !forced && config().k64_tile < 0; // OZIMMU_HIP_K64_TILE=1 / the forced kernel: no exceptions
-          const uint64_t tn128 = (a.N + 127) / 128;
-          const bool one_round = (uint64_t)(pl.n_big + pl.n_small) * tn128 <= (uint64_t)ncu_eff &&
-                                 (uint64_t)(plk.n_big + plk.n_small) * tn128 > (uint64_t)ncu_eff;
-          const bool fewer_rounds = by_policy && K64Cfg<ND>::WA < WideCfg<S, D0, ND>::WA &&
-                                    (one_round || plk.makespan * 0.92 > pl.makespan);
-          if (!fewer_rounds) {
-            pl = plk;
-            return Pick::WIDE_K64;
-          }
-        }
-      }
-      if constexpr (PairedCfg<S, D0, ND>::ok) {
-        // OZIMMU_HIP_GEMM_KERNEL=x16 / wide: force the paired (16x16x64) / the 32x32x32 tile function
-        if (forced ? config().gemm_kernel == Config::X16 : paired_tile_default(SL)) return Pick::WIDE_X16;
-      }
-      return Pick::WIDE;
-    }
-  }
-  return Pick::CLASSIC;
+  t.classic_wm4 = S <= 6 && D0 == 0 && ND == S;
+  t.classic_form = (t.SL >= 11 && t.SL <= 13) ? 1 : (t.SL >= 14 ? 2 : 0); // launch_one: WM by staged slices (LDS)
+  return t;
 }
 
-template <int S, int D0, int ND, int FORCE_WM = 0>
+// kernel choice for one pass over the diagonals [D0, D0 + ND): the cost model of kernel_policy.cpp predicts every kernel the
+// pass is built for and takes the fastest (OZIMMU_HIP_GEMM_KERNEL / _K64_TILE / _PAIRED_TILE / _K64_BREG override).  `pl`: the
+// tile plan of the chosen wide kernel; `breg`: k64 with the B fragments in registers; `wm4`: the classic kernel's 128x64 form.
+template <int S, int D0, int ND>
+static Pick pick_kernel(const SliceGemmArgs &a, WidePlan &pl, bool &breg, bool &wm4) {
+  constexpr PassTraits t = pass_traits<S, D0, ND>();
+  PolicyInput in;
+  in.M = a.M;
+  in.N = a.N;
+  in.nkb = a.kb1 - a.kb0;
+  in.batch = a.batch > 1 ? a.batch : 1;
+  const Prediction r = policy_predict(t, in, topology(), config());
+  pl = r.plan[r.breg ? 5 : (int)r.pick];
+  breg = r.breg;
+  wm4 = r.classic_wm4;
+  return r.pick;
+}
+
+template <int S, int D0, int ND>
 static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
   WidePlan pl;
-  switch (pick_kernel<S, D0, ND>(a, pl)) {
+  bool breg = false, wm4 = false;
+  const Pick pick = pick_kernel<S, D0, ND>(a, pl, breg, wm4);
+  note_pick(D0 > 0 ? 1 : 0, (int)pick + (breg ? 8 : 0)); // diagnostics: ozimmu_hip_last_kernel
+  switch (pick) {
   case Pick::K2:
     if constexpr (K2Cfg<S, D0, ND>::ok) return launch_k2<S, D0, ND>(a, stream);
     break;
   case Pick::WIDE_K64:
-    if constexpr (D0 == 0 && K64Cfg<ND>::ok) return launch_wide_k64<S, ND>(a, pl, stream);
+    if constexpr (D0 == 0 && K64Cfg<ND>::ok) return launch_wide_k64<S, ND>(a, pl, breg, stream);
     break;
   case Pick::WIDE_X16:
     if constexpr (WideCfg<S, D0, ND>::ok && PairedCfg<S, D0, ND>::ok) return launch_wide<S, D0, ND, true>(a, pl, stream);
@@ -448,7 +349,11 @@ static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
   default:
     break;
   }
-  return launch_one<S, D0, ND, FORCE_WM>(a, stream);
+  if constexpr (S <= 6 && D0 == 0 && ND == S) {
+    // few slices = few MFMAs per staged byte: the 128x64 8-wave workgroup (-25 % staged bytes) once there are enough tiles
+    if (wm4) return launch_one<S, D0, ND, 4>(a, stream);
+  }
+  return launch_one<S, D0, ND>(a, stream);
 }
 
 // The real products of a ZGEMM (2..4 slice GEMMs that accumulate into the same C in the given order, each a single diagonal
@@ -466,7 +371,9 @@ static hipError_t launch_fused(const SliceGemmArgs *g, int count, hipStream_t st
       if (g[i].M != a0.M || g[i].N != a0.N || g[i].batch != a0.batch || g[i].kb0 != a0.kb0 || g[i].kb1 != a0.kb1)
         return hipErrorNotSupported;
     WidePlan pl;
-    const Pick pick = pick_kernel<S, 0, S>(a0, pl);
+    bool breg = false, wm4 = false;
+    const Pick pick = pick_kernel<S, 0, S>(a0, pl, breg, wm4);
+    note_pick(0, (int)pick + (breg ? 8 : 0));
     if (pick == Pick::K2) return launch_k2_fused<S>(g, count, stream);
     // (S = 7 keeps 448 accumulator registers per wave: walking several argument sets per tile spills inside its k loop)
     if constexpr (WideCfg<S, 0, S>::ok && WideCfg<S, 0, S>::WA * S * 16 <= 432) {
@@ -476,7 +383,7 @@ static hipError_t launch_fused(const SliceGemmArgs *g, int count, hipStream_t st
       const uint64_t tiles = (uint64_t)(pl.n_big + pl.n_small) * ((a0.N + 127) / 128);
       const bool few_tiles = tiles <= 8ull * (uint64_t)cu_count() || config().wide_grid > 0;
       if constexpr (K64Cfg<S>::ok) {
-        if (pick == Pick::WIDE_K64 && a0.batch <= 1 && a0.phase && few_tiles) return launch_wide_multi_k64<S>(g, count, pl, stream);
+        if (pick == Pick::WIDE_K64 && a0.batch <= 1 && a0.phase && few_tiles) return launch_wide_multi_k64<S>(g, count, pl, breg, stream);
       }
       if ((pick == Pick::WIDE || pick == Pick::WIDE_X16) && a0.batch <= 1 && a0.phase && few_tiles)
         return launch_wide_multi<S>(g, count, pl, pick == Pick::WIDE_X16, stream);
@@ -490,11 +397,6 @@ static hipError_t launch_fused(const SliceGemmArgs *g, int count, hipStream_t st
 template <int S>
 static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
   if constexpr (S <= SINGLE_PASS_MAX_S) {
-    if constexpr (S <= 6) {
-      // few slices = few MFMAs per staged byte: the 128x64 8-wave workgroup (-25 % staged bytes) wins once there
-      // are enough tiles to fill the chip (4096^3: S=3 +8 %, S=4 +18 %, S=5 +10 %, S=6 +7 %; S=7 +1 %, S=8 -2 %)
-      if ((size_t)((a.M + 127) / 128) * ((a.N + 63) / 64) >= 512) return launch_pass<S, 0, S, 4>(a, stream);
-    }
     return launch_pass<S, 0, S>(a, stream);
   } else {
     constexpr int ND1 = (S + 1) / 2, ND2 = S - ND1;
@@ -522,6 +424,27 @@ static hipError_t dispatch_S(int s, const SliceGemmArgs &a, hipStream_t stream) 
 }
 
 hipError_t OZ_PART(int S, const SliceGemmArgs &a, hipStream_t stream) { return dispatch_S<OZ_S_LO>(S, a, stream); }
+
+// the traits of mode S's passes (pass 0: the single / first pass, 1: the second pass of S > 12) for the diagnostics of api.cpp
+template <int S>
+static bool traits_S(int s, int pass, PassTraits *out) {
+  if constexpr (S > OZ_S_HI) {
+    return false;
+  } else {
+    if (s != S) return traits_S<S + 1>(s, pass, out);
+    if constexpr (S <= SINGLE_PASS_MAX_S) {
+      if (pass != 0) return false;
+      *out = pass_traits<S, 0, S>();
+    } else {
+      constexpr int ND1 = (S + 1) / 2, ND2 = S - ND1;
+      if (pass == 0) *out = pass_traits<S, 0, ND1>();
+      else if (pass == 1) *out = pass_traits<S, ND1, ND2>();
+      else return false;
+    }
+    return true;
+  }
+}
+bool OZ_PART_TRAITS(int S, int pass, PassTraits *out) { return traits_S<OZ_S_LO>(S, pass, out); }
 
 template <int S>
 static hipError_t dispatch_fused_S(int s, const SliceGemmArgs *g, int count, hipStream_t stream) {

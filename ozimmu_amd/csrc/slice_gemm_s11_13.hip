@@ -3,4 +3,5 @@
 #define OZ_S_HI 13
 #define OZ_PART launch_slice_gemm_s11_13
 #define OZ_PART_FUSED launch_slice_gemm_fused_s11_13
+#define OZ_PART_TRAITS slice_gemm_traits_s11_13
 #include "slice_gemm_launch.h"

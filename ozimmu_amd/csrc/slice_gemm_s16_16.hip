@@ -3,4 +3,5 @@
 #define OZ_S_HI 16
 #define OZ_PART launch_slice_gemm_s16_16
 #define OZ_PART_FUSED launch_slice_gemm_fused_s16_16
+#define OZ_PART_TRAITS slice_gemm_traits_s16_16
 #include "slice_gemm_launch.h"

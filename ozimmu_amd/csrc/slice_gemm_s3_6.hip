@@ -3,4 +3,5 @@
 #define OZ_S_HI 6
 #define OZ_PART launch_slice_gemm_s3_6
 #define OZ_PART_FUSED launch_slice_gemm_fused_s3_6
+#define OZ_PART_TRAITS slice_gemm_traits_s3_6
 #include "slice_gemm_launch.h"

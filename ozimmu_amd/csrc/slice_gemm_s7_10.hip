@@ -3,4 +3,5 @@
 #define OZ_S_HI 10
 #define OZ_PART launch_slice_gemm_s7_10
 #define OZ_PART_FUSED launch_slice_gemm_fused_s7_10
+#define OZ_PART_TRAITS slice_gemm_traits_s7_10
 #include "slice_gemm_launch.h"

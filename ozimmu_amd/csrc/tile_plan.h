@@ -104,4 +104,33 @@ inline WidePlan plan_wide_with(uint32_t M, uint32_t N, int WA, int ncu, Sim sim)
 }
 inline WidePlan plan_wide(uint32_t M, uint32_t N, int WA, int ncu) { return plan_wide_with(M, N, WA, ncu, simulate_rounds); }
 
+// The same search with the tile costs of the caller's model (kernel_policy.cpp): a tile of h blocks costs cost(h) in the
+// caller's unit (microseconds); makespan in that unit.
+template <class Cost>
+inline WidePlan plan_wide_costs(uint32_t M, uint32_t N, int WA, int ncu, Cost cost) {
+  const uint32_t rows32 = (M + 31) / 32, tn = (N + 127) / 128;
+  const double cbig = cost(WA), csmall = WA > 1 ? cost(WA - 1) : cbig;
+  WidePlan best;
+  const uint32_t max_small = WA > 1 ? (rows32 + (WA - 2)) / (WA - 1) : 0;
+  auto eval = [&](uint32_t n2) {
+    const uint32_t covered = (uint32_t)(WA - 1) * n2;
+    const uint32_t n3 = covered >= rows32 ? 0 : (rows32 - covered + WA - 1) / WA;
+    const double t = simulate_rounds((uint64_t)n3 * tn, cbig, (uint64_t)n2 * tn, csmall, ncu);
+    if (best.makespan == 0 || t < best.makespan - 1e-9) {
+      best.n_big = n3;
+      best.n_small = n2;
+      best.makespan = t;
+    }
+    return n3;
+  };
+  if (config().wide_small_rows >= 0) { // measurement override: rows of reduced-height tiles
+    eval(std::min<uint32_t>((uint32_t)config().wide_small_rows, max_small));
+  } else {
+    for (uint32_t n2 = 0; n2 <= max_small; n2++)
+      if (eval(n2) == 0) break;
+  }
+  best.efficiency = cbig > 0 ? (double)rows32 * tn * (cbig / WA) / (best.makespan * ncu) : 0;
+  return best;
+}
+
 } // namespace ozhip

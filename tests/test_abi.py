@@ -211,3 +211,41 @@ def test_tile_plan_closed_form_matches_the_literal_dispatch_simulation(lib):
     assert time.perf_counter() - t0 < 2e-3                                        # was 22 ms
     assert lib.ozimmu_hip_tile_plan(0, 5, 2, 256, 0, out_new) == 1
     assert lib.ozimmu_hip_tile_plan(5, 5, 0, 256, 0, out_new) == 1
+
+
+def test_kernel_choice_cost_model_is_host_arithmetic(lib):
+    """csrc/kernel_policy.cpp: the launch policy predicts the time of every kernel a pass is built for and takes the fastest.
+    The prediction needs no GPU (NULL handle = the nominal 256-CU device): eligibility follows the kernels' constraints, the
+    pick is the minimum, a forced kernel wins where it exists, and the constants can be read and replaced at run time."""
+    pred, pick = ozimmu_amd.policy_predict(None, 9, 8192, 8192, 8192)
+    assert set(pred) == {"classic", "wide", "k64", "k64_breg"}          # K-split: at most one 64x64 tile per CU; x16: S >= 10
+    assert pick == min(pred, key=pred.get) == "k64_breg"                 # the headline shape runs the k64 tile, B in registers
+    assert 10e3 < pred["k64_breg"] < 20e3                                # ~14 ms
+    pred, pick = ozimmu_amd.policy_predict(None, 9, 8192, 8192, 8192 + 64)   # k-blocks = 2 mod 4: no register form
+    assert "k64_breg" not in pred and "k64" in pred
+    pred, _ = ozimmu_amd.policy_predict(None, 9, 8192, 8192, 8192 + 32)      # (planes pad odd k-block counts beyond 32 to even)
+    assert "k64" in pred
+    pred, _ = ozimmu_amd.policy_predict(None, 9, 512, 512, 96)               # 3 k-blocks: no k64 tile; few tiles: K-split exists
+    assert "k64" not in pred and "k2" not in pred                           # (K-split needs 4+ k-blocks)
+    pred, pick = ozimmu_amd.policy_predict(None, 9, 1024, 1024, 1024)
+    assert "k2" in pred and pick == min(pred, key=pred.get)
+    k2_before = pred["k2"]
+    pred, _ = ozimmu_amd.policy_predict(None, 13, 4096, 4096, 4096, pass_index=1)   # second diagonal pass: no k64 tile
+    assert "k64" not in pred and "wide" in pred
+    with pytest.raises(RuntimeError):
+        ozimmu_amd.policy_predict(None, 9, 4096, 4096, 4096, pass_index=1)    # fp64_int8_9 has one pass
+    # time grows with the work
+    t = [min(ozimmu_amd.policy_predict(None, 9, n, n, n)[0].values()) for n in (1024, 2048, 4096, 8192)]
+    assert t == sorted(t) and t[3] / t[2] > 6
+    # the table can be replaced (tools/policy_fit.py does that in its loop) and restored
+    p0 = ozimmu_amd.policy_params()
+    assert len(p0) == ozimmu_amd.POLICY_PARAMS
+    p1 = list(p0)
+    p1[0] *= 2                                                               # K-split: twice as slow per MFMA
+    ozimmu_amd.policy_params(p1)
+    try:
+        assert ozimmu_amd.policy_predict(None, 9, 1024, 1024, 1024)[0]["k2"] > 1.3 * k2_before
+        assert ozimmu_amd.policy_params()[0] == p1[0]
+    finally:
+        ozimmu_amd.policy_params(p0)
+    assert ozimmu_amd.policy_params() == p0

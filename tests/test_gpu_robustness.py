@@ -531,3 +531,28 @@ def test_epoch_wrap_around_with_a_captured_graph_in_flight(monkeypatch):
     finally:
         torch.cuda.synchronize()
         oz_t.destroy(h)
+
+
+def test_the_policy_runs_what_it_predicts_and_reports_it(oz, monkeypatch):
+    """ozimmu_hip_last_kernel / ozimmu_hip_policy_predict: the kernel a call ran is the one the cost model picked for its
+    shape on this device; a forced kernel is reported as such; every choice gives the oracle's bits (the forced-kernel fuzz
+    of test_gpu_parity.py), here: the report."""
+    import torch
+    m_, h = oz
+    info = m_.device_info(h)
+    assert info["cus"] >= 1 and info["xcds"] >= 1 and 0.75 * 0.0194 <= info["mfma32_us"] <= 1.25 * 0.0194
+    for (m, n, k, S) in [(1024, 1024, 1024, 9), (512, 384, 2048, 6), (2048, 1536, 256, 4), (700, 900, 1024, 13)]:
+        a = torch.rand(k, m, dtype=torch.float64, device="cuda")
+        b = torch.rand(n, k, dtype=torch.float64, device="cuda")
+        c = torch.zeros(n, m, dtype=torch.float64, device="cuda")
+        monkeypatch.delenv("OZIMMU_HIP_GEMM_KERNEL", raising=False)
+        assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c, m, f"fp64_int8_{S}") == 0
+        torch.cuda.synchronize()
+        ran = m_.last_kernel(h)
+        pred, pick = m_.policy_predict(h, S, m, n, k)
+        assert ran[0] == pick and pick == min(pred, key=pred.get), (ran, pick, pred)
+        assert (ran[1] is None) == (S <= 12)
+        monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", "classic")
+        assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c, m, f"fp64_int8_{S}") == 0
+        torch.cuda.synchronize()
+        assert m_.last_kernel(h)[0] == "classic"

@@ -43,6 +43,11 @@ def preset(name, rng_mod=None):
         return [(s, None) for s in [(8192, 8192, 128), (8192, 8192, 256), (8192, 8192, 384), (8192, 8192, 512),
                                     (16384, 16384, 128), (16384, 16384, 256), (4096, 4096, 128), (4096, 4096, 256),
                                     (4096, 4096, 512), (4096, 4096, 1024), (2048, 2048, 512), (32768, 32768, 256)]]
+    if name == "bench":  # the cases of bench.py's extra.policy_regret
+        return [((4096, 4096, 1024), "fp64_int8_9"), ((2048, 2048, 2048), "fp64_int8_9"), ((1024, 1024, 1024), "fp64_int8_9"),
+                ((3000, 5000, 512), "fp64_int8_6"), ((4096, 4096, 256), "fp64_int8_4"), ((2500, 1800, 2048), "fp64_int8_12"),
+                ((8192, 8192, 256), "fp64_int8_9"), ((1536, 1536, 1536), "fp64_int8_8"), ((6000, 3000, 128), "fp64_int8_8"),
+                ((900, 1300, 4096), "fp64_int8_6")]
     if name == "panel":
         return [((m, m, k), None) for m in (8192, 16384) for k in (128, 256, 512, 1024, 2048)]
     if name.startswith("random"):
@@ -157,7 +162,7 @@ def policy_regret(harness, cases, forced=("k2", "classic", "wide", "k64"), legs=
         med, _ = harness.time_shape(shape, mode, ["auto"] + list(forced), legs=legs, leg_seconds=leg_seconds)
         best = min(forced, key=lambda v: med[v])
         rows.append({"shape": "x".join(map(str, shape)), "mode": mode, "best": best,
-                     "regret_pct": round((med["auto"] / med[best] - 1) * 100, 2)})
+                     "regret_pct": round(max(0.0, (med["auto"] / med[best] - 1) * 100), 2)})
     r = sorted(x["regret_pct"] for x in rows)
     return {"cases": len(rows), "median_pct": r[len(r) // 2], "max_pct": r[-1], "over_3pct": sum(1 for x in r if x > 3.0),
             "worst": sorted(rows, key=lambda x: -x["regret_pct"])[:3], "forced_kernels": list(forced)}
@@ -175,11 +180,19 @@ def main():
     ap.add_argument("--legs", type=int, default=4)
     ap.add_argument("--leg-seconds", type=float, default=0.3)
     ap.add_argument("--losses", type=float, default=None, help="list the cases where variant 1 loses more than this many %% of time")
+    ap.add_argument("--regret-json", action="store_true",
+                    help="print ONE JSON object: the policy's regret against every forced kernel over the cases (bench.py)")
     args = ap.parse_args()
     cases = [(parse_shape(s), None) for s in args.shapes] + (preset(args.preset) if args.preset else [])
     if not cases:
         raise SystemExit("no shapes: --shapes or --preset")
     H = Harness()
+    if args.regret_json:
+        import json
+        fixed = [(sh, md or args.modes[0]) for sh, md in cases]
+        print(json.dumps(policy_regret(H, fixed, legs=max(1, min(args.legs, 2)), leg_seconds=min(args.leg_seconds, 0.08))), flush=True)
+        H.close()
+        return
     losses = []
     for shape, fixed_mode in cases:
         for mode in ([fixed_mode] if fixed_mode else args.modes):
