@@ -41,6 +41,8 @@ struct SliceGemmArgs {
   uint32_t *queue;
   uint32_t qslot; // set by the host pipeline: counter pair for this launch (a call may need several launches)
   uint32_t phase_min_kb; // passes of at most this many k-blocks run without the phase hint (filled in by launch_slice_gemm)
+  uint32_t spec_claim_kb; // persistent k64 kernels: passes of at most this many k-blocks draw the next tile's ticket one tile ahead
+                          // (slice_gemm_w_kernel.h; filled in by launch_slice_gemm; 0: never)
   uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
   // test hook, compiled only with -DOZIMMU_HIP_TEST_HOOKS (the default, in-tree build that the test-suite loads;
   // `python -m ozimmu_amd.build --release` builds libozimmu_hip_release.so without any hook): INT32 diagonal sums

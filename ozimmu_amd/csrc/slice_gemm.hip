@@ -107,6 +107,7 @@ hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g_in, int count, 
     g[i] = g_in[i];
     g[i].nxcd = nx;
     g[i].phase_min_kb = (uint32_t)config().phase_min_kb;
+    g[i].spec_claim_kb = (uint32_t)config().spec_claim_kb;
   }
   if (S >= 3 && S <= 6) return launch_slice_gemm_fused_s3_6(S, g, count, stream);
   if (S >= 7 && S <= 10) return launch_slice_gemm_fused_s7_10(S, g, count, stream);
@@ -118,6 +119,7 @@ hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a_in, hipStream_t strea
   SliceGemmArgs a = a_in;
   a.nxcd = (uint32_t)topology().xcds; // the kernels' tile partition and per-XCD lines follow the device (topology.h)
   a.phase_min_kb = (uint32_t)config().phase_min_kb;
+  a.spec_claim_kb = (uint32_t)config().spec_claim_kb;
   if (S >= 3 && S <= 6) return launch_slice_gemm_s3_6(S, a, stream);
   if (S >= 7 && S <= 10) return launch_slice_gemm_s7_10(S, a, stream);
   if (S >= 11 && S <= 13) return launch_slice_gemm_s11_13(S, a, stream);

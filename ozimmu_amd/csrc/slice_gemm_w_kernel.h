@@ -569,6 +569,12 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
     xcd = __builtin_amdgcn_readfirstlane((x & 0xfu) % nx);
   }
   const uint32_t small_shift = nbig % nx; // the small region's runs are rotated by the big region's remainder
+  // speculative claim (see below): only the k64 kernels with at most 320 accumulator registers carry its five extra live
+  // values through their k loop without spilling (the 432 / 448-register kernels flip into scratch on ONE more: DESIGN.md 4.2)
+  constexpr bool SPECULATE = !MULTI && (VARW & VARW_K64) != 0 && 2 * WA * 2 * ND * 4 <= 320 &&
+                             (VARW & (VARW_TRACE | VARW_NO_GLOBAL | VARW_MFMA_ONLY)) == 0;
+  uint32_t spec_region = 0, spec_from = 0, spec_len = 0, spec_start = 0, spec_t = 0; // meaningful in thread 0 only
+  uint32_t *spec_cnt = nullptr;
   for (;;) {
     uint32_t kind = 0, lid = 0; // 1: big tile `lid` of its region, 2: small tile, 0: nothing left
     if (!p.queue) {
@@ -585,7 +591,15 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
       __syncthreads(); // the previous tile's LDS reads are done
       if (threadIdx.x == 0) {
         uint32_t k = 0, l = 0;
-
+        if constexpr (SPECULATE) {
+          if (spec_region) { // the ticket drawn at the start of the previous tile (below): long back by now
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(spec_t));
+            if (spec_t < spec_len) {
+              k = spec_region;
+              l = spec_start + spec_t;
+            }
+          }
+        }
         for (uint32_t region = 1; region <= 2 && !k; region++) {
           const uint32_t n = region == 1 ? nbig : nsmall;
           for (uint32_t v = 0; v < nx && !k; v++) { // own run first, then the neighbours'
@@ -597,11 +611,31 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
             if (t < len) {
               k = region;
               l = xcd_run_start(xr, n, nx) + t;
+              if constexpr (SPECULATE) { // where this tile came from is where the next ticket is drawn
+                spec_cnt = cnt;
+                spec_len = len;
+                spec_start = xcd_run_start(xr, n, nx);
+                spec_from = region;
+              }
             }
           }
         }
         reinterpret_cast<volatile uint32_t *>(smem)[0] = k;
         reinterpret_cast<volatile uint32_t *>(smem)[1] = l;
+        if constexpr (SPECULATE) {
+          // Short k loops (K <= 2048): a tile lasts tens of microseconds and the ~2 us round trips of its claim (a device-scope
+          // load and a fetch-add, nothing else running on the CU) are a few percent of it.  Draw the NEXT tile's ticket now,
+          // from the counter this tile came from, and look at the result at the next boundary: its round trip hides under
+          // the whole k loop (the asm statement returns at once; the tile's own vmcnt(0) waits cover it).  A ticket beyond
+          // the run's end is harmless (readers compare with >=); the full claim above then looks elsewhere.  At most one tile
+          // per workgroup is held early, so the stealing granularity suffers by less than one short tile at the kernel's end.
+          spec_region = 0;
+          if (k && spec_from == k && p.kb1 - p.kb0 <= p.spec_claim_kb) {
+            spec_region = k;
+            const uint32_t one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(spec_t) : "v"(spec_cnt), "v"(one) : "memory");
+          }
+        }
       }
       __syncthreads();
       kind = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile uint32_t *>(smem)[0]);

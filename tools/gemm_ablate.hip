@@ -161,6 +161,7 @@ int main(int argc, char **argv) {
   a.phase = phase;
   a.nxcd = 8;
   a.phase_min_kb = 32;
+  a.spec_claim_kb = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 64u; // argv[6]: claim-ahead threshold in k-blocks (0: off)
 
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -345,6 +346,13 @@ int main(int argc, char **argv) {
       {"k64 64x128 B->VGPR no copies", run_w<S, 2, Z | VARW_NO_GLOBAL, 0, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 B via LDS no copies", run_w<S, 2, Y | VARW_NO_GLOBAL, 0, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 mfma only", run_w<S, 2, Y | VARW_MFMA_ONLY, 0, -1, 8, 12, false, true>, false, {}},
+#elif ABLATE_BREG_PART == 4 // tile boundaries (run with a short K: tools/bin/gemm_ablate_breg4 8192 7 127 8192 512)
+      {"k64 64x128 B->VGPR persistent, claim one tile ahead", run_w<S, 2, Z, 0, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR static grid (no claims)", run_w<S, 2, Z, 0, -1, 8, 12, false, false>, false, {}},
+      {"k64 64x128 B->VGPR persistent, no epilogue", run_w<S, 2, Z | VARW_NO_EPILOGUE, 0, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 B->VGPR static, no epilogue", run_w<S, 2, Z | VARW_NO_EPILOGUE, 0, -1, 8, 12, false, false>, false, {}},
+      {"k64 64x128 B->VGPR persistent, epilogue w/o stores", run_w<S, 2, Z | VARW_EPI_NOSTORE, 0, -1, 8, 12, false, true>, false, {}},
+      {"k64 64x128 mfma only (persistent)", run_w<S, 2, Y | VARW_MFMA_ONLY, 0, -1, 8, 12, false, true>, false, {}},
 #elif ABLATE_BREG_PART == 3 // what the step's waits cost (wrong results)
       {"k64 64x128 B->VGPR without the vmcnt wait", run_w<S, 2, Z, 100, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 B->VGPR without the lgkmcnt wait", run_w<S, 2, Z, 200, -1, 8, 12, false, true>, false, {}},
