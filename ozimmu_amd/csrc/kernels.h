@@ -44,8 +44,8 @@ struct SliceGemmArgs {
   uint32_t spec_claim_kb; // persistent k64 kernels: passes of at most this many k-blocks draw the next tile's ticket one tile ahead
                           // (slice_gemm_w_kernel.h; filled in by launch_slice_gemm; 0: never)
   uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
-  // test hook, compiled only with -DOZIMMU_HIP_TEST_HOOKS (the default, in-tree build that the test-suite loads;
-  // `python -m ozimmu_amd.build --release` builds libozimmu_hip_release.so without any hook): INT32 diagonal sums
+  // test hook, compiled only with -DOZIMMU_HIP_TEST_HOOKS (libozimmu_hip_test.so, loaded by the tests that need a hook; the
+  // library that ships, libozimmu_hip.so, carries none: ozimmu_amd/build.py): INT32 diagonal sums
   // [S][N][M] instead of / besides the FP64 epilogue.  The fields stay in both flavours (one argument layout).
   int32_t *dump;
   int dump_only;

@@ -346,6 +346,9 @@ int main(int argc, char **argv) {
       {"k64 64x128 B->VGPR no copies", run_w<S, 2, Z | VARW_NO_GLOBAL, 0, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 B via LDS no copies", run_w<S, 2, Y | VARW_NO_GLOBAL, 0, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 mfma only", run_w<S, 2, Y | VARW_MFMA_ONLY, 0, -1, 8, 12, false, true>, false, {}},
+#elif ABLATE_BREG_PART == 5 // -DABLATE_S=8 (or 7): the 64x128 B-in-registers form against the 96x128 LDS form of fewer slices
+      {"k64 96x128 B via LDS (shipped for S = 7, 8)", run_w<S, 3, Y, 0, -1, 8, 12, true, true>, false, {}},
+      {"k64 64x128 B via LDS", run_w<S, 2, Y, 0, -1, 8, 12, false, true>, false, {}},
 #elif ABLATE_BREG_PART == 4 // tile boundaries (run with a short K: tools/bin/gemm_ablate_breg4 8192 7 127 8192 512)
       {"k64 64x128 B->VGPR persistent, claim one tile ahead", run_w<S, 2, Z, 0, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 B->VGPR static grid (no claims)", run_w<S, 2, Z, 0, -1, 8, 12, false, false>, false, {}},
