@@ -157,7 +157,13 @@ static uint32_t wide_grid(SliceGemmArgs &a, const WidePlan &pl) {
   uint32_t nb = (a.tiles_m + a.tiles_m2) * a.tiles_n;
   a.queue = nullptr;
   const uint32_t max_slots = (PHASE_LINE_WORDS - 16) / 2; // words 16 .. 63 of a phase line
-  if (a.phase && a.batch <= 1 && a.qslot < max_slots && nb > (uint32_t)cu_count() && !config().wide_static) {
+  // A few EXACT rounds of tiles (2048^3: 512 tiles of 64 x 128, 4096^3: 2048): nothing to balance, and the static grid - the
+  // dispatcher hands the workgroups out in order - saves every tile the round trips of its claim: +1.1 ... 1.4 % at 2 tiles
+  // per CU, +0.5 % at 8 and 18; from 32 per CU on the persistent workgroups win (8192^3 +0.7 %, 16384^2 x 1024 +2.2 %: the
+  // claimed order keeps an XCD's workgroups on neighbouring panels).  profiles/r4_ablate/r4r_static_grid_vs_queue_ab.txt
+  const uint32_t cus = (uint32_t)cu_count();
+  const bool exact_few_rounds = nb % cus == 0 && nb / cus <= (uint32_t)std::max(0, config().static_rounds) && config().wide_grid == 0;
+  if (a.phase && a.batch <= 1 && a.qslot < max_slots && nb > cus && !config().wide_static && !exact_few_rounds) {
     a.queue = a.phase + 16 + 2 * a.qslot;
     nb = (uint32_t)cu_count();
     if (config().wide_grid > 0) nb = (uint32_t)config().wide_grid; // tests: few workgroups, many tiles each

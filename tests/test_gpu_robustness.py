@@ -556,3 +556,29 @@ def test_the_policy_runs_what_it_predicts_and_reports_it(oz, monkeypatch):
         assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c, m, f"fp64_int8_{S}") == 0
         torch.cuda.synchronize()
         assert m_.last_kernel(h)[0] == "classic"
+
+
+@pytest.mark.parametrize("m,n,k,S", [(2048, 2048, 1024, 9), (1024, 4096, 2048, 9), (3072, 2048, 1024, 7), (2048, 4096, 1024, 6)])
+def test_static_grid_for_exact_rounds_equals_the_queue_run(oz, monkeypatch, m, n, k, S):
+    """slice_gemm_launch.h: wide_grid - a few EXACT rounds of tiles run as a static grid (no claims), everything else as
+    persistent workgroups with claim counters.  Same tiles, same arithmetic: the bits of the static run equal those of the
+    queue run (forced by OZIMMU_HIP_WIDE_GRID = the CU count), and the residual is the mode's."""
+    import torch
+    m_, h = oz
+    torch.manual_seed(m + n + k + S)
+    a = torch.rand(k, m, dtype=torch.float64, device="cuda") * 2 - 1
+    b = torch.rand(n, k, dtype=torch.float64, device="cuda") * 2 - 1
+    out = []
+    for grid in (None, str(m_.device_info(h)["cus"])):
+        if grid is None:
+            monkeypatch.delenv("OZIMMU_HIP_WIDE_GRID", raising=False)
+        else:
+            monkeypatch.setenv("OZIMMU_HIP_WIDE_GRID", grid)
+        c = torch.full((n, m), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c, m, f"fp64_int8_{S}") == 0
+        torch.cuda.synchronize()
+        out.append(c)
+    assert torch.equal(out[0].view(torch.int64), out[1].view(torch.int64))
+    ref = b @ a
+    assert ((out[0] - ref).norm() / ref.norm()).item() < (1e-14 if S >= 9 else 1e-8)
