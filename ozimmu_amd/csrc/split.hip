@@ -33,7 +33,6 @@
 
 namespace ozhip {
 
-static constexpr unsigned long long MANT_MASK = 0x000FFFFFFFFFFFFFull;
 
 __device__ __forceinline__ unsigned exp_field(double x) {
   return (unsigned)((unsigned long long)__double_as_longlong(x) >> 52) & 0x7FFu;
