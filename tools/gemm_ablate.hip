@@ -356,6 +356,12 @@ int main(int argc, char **argv) {
       {"k64 64x128 B->VGPR static, no epilogue", run_w<S, 2, Z | VARW_NO_EPILOGUE, 0, -1, 8, 12, false, false>, false, {}},
       {"k64 64x128 B->VGPR persistent, epilogue w/o stores", run_w<S, 2, Z | VARW_EPI_NOSTORE, 0, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 mfma only (persistent)", run_w<S, 2, Y | VARW_MFMA_ONLY, 0, -1, 8, 12, false, true>, false, {}},
+#elif ABLATE_BREG_PART == 6 // small problems (run: tools/bin/gemm_ablate_breg6 1024 9): what bounds the half-height (32 x 128) tile's k loop
+      {"k64 32x128 B->VGPR static grid", run_w<S, 1, Z, 0, -1, 8, 12, false, false>, false, {}},
+      {"k64 32x128 B->VGPR static grid, no copies", run_w<S, 1, Z | VARW_NO_GLOBAL, 0, -1, 8, 12, false, false>, false, {}},
+      {"k64 32x128 B->VGPR static grid, no epilogue", run_w<S, 1, Z | VARW_NO_EPILOGUE, 0, -1, 8, 12, false, false>, false, {}},
+      {"k64 32x128 mfma only", run_w<S, 1, Y | VARW_MFMA_ONLY, 0, -1, 8, 12, false, false>, false, {}},
+      {"k64 64x128 B->VGPR static grid, no copies", run_w<S, 2, Z | VARW_NO_GLOBAL, 0, -1, 8, 12, false, false>, false, {}},
 #elif ABLATE_BREG_PART == 3 // what the step's waits cost (wrong results)
       {"k64 64x128 B->VGPR without the vmcnt wait", run_w<S, 2, Z, 100, -1, 8, 12, false, true>, false, {}},
       {"k64 64x128 B->VGPR without the lgkmcnt wait", run_w<S, 2, Z, 200, -1, 8, 12, false, true>, false, {}},
