@@ -107,6 +107,16 @@ int ozimmu_hip_device_info(ozimmu_hip_handle_t handle, double out[4]);
 int ozimmu_hip_policy_predict(ozimmu_hip_handle_t handle, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
                               double out_us[6], int *pick);
 int ozimmu_hip_policy_params(double *params, int count, int set);
+/* The launch policy is bound to the DEVICE ID a handle was created on, never to "the current device" of the calling thread
+ * (the reference keeps one global handle for one device: src/cublas.cu:58; a process that drives several GPUs through this
+ * library gets one handle - workspace, topology, kernel attributes - per device).
+ * ozimmu_hip_device_topology: set = 0: inout = {CUs, XCDs, planned MFMA time, measured MFMA time} of slot `device` (what
+ *   ozimmu_hip_device_info returns for a handle of that device; nominal values until a handle was created there); set = 1:
+ *   replace the slot - test flavour only (fake devices on a box without a GPU), the library that ships returns 2.
+ * ozimmu_hip_policy_predict_device: ozimmu_hip_policy_predict with the topology of slot `device`. */
+int ozimmu_hip_device_topology(int device, double inout[4], int set);
+int ozimmu_hip_policy_predict_device(int device, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
+                                     double out_us[6], int *pick);
 int ozimmu_hip_last_kernel(ozimmu_hip_handle_t handle, int out[2]);
 int ozimmu_hip_destroy(ozimmu_hip_handle_t handle);
 

@@ -80,6 +80,10 @@ def build(force=False, verbose=False, test_flavour=True, product=True):
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     flavours = [_flavour(h) for h in ([False] if product else []) + ([True] if test_flavour else [])]
     jobs = []
+    all_src = [os.path.join(CSRC, s) for s in SOURCES] + deps
+    # a library newer than every source is current even where its objects are absent (the GPU box: build/ and build_test/ -
+    # objects and kept assembly, 200 MB - are listed in .gpurunignore and do not travel with the snapshot)
+    flavours = [f for f in flavours if force or _stale(f[3], all_src)]
     for bdir, common, objs, _ in flavours:
         os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
         jobs += [(common, s, bdir) for s, obj in zip(SOURCES, objs) if force or _stale(obj, [os.path.join(CSRC, s)] + deps)]

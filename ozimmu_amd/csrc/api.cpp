@@ -335,7 +335,7 @@ static bool exp_words(ozimmu_hip_handle_t h, size_t m, size_t n, int parts, size
 
 // the phase hints / claim counters of a call: one 256-byte line per XCD that the slice GEMM expects zeroed
 static bool zero_phase_lines(ozimmu_hip_handle_t h, uint32_t *phase) {
-  return hip_ok(launch_zero_words(phase, (size_t)topology().xcds * PHASE_LINE_WORDS * 4, 0, 1, h->stream), "zero_words");
+  return hip_ok(launch_zero_words(phase, (size_t)topology(h->device).xcds * PHASE_LINE_WORDS * 4, 0, 1, h->stream), "zero_words");
 }
 
 // The per-XCD phase hints and the tile queues of the persistent wide kernel only pay for problems with more tiles than
@@ -343,8 +343,11 @@ static bool zero_phase_lines(ozimmu_hip_handle_t h, uint32_t *phase) {
 // and the call saves the zeroing launch: three launches per small DGEMM (row maxima, cut, GEMM).
 // Nor for a short K: with fewer than 32 k-steps per tile the claim of a tile and the read of the hint cost more than
 // stealing and phase alignment return (8192^2 x 128..512: 3-6 % slower with them, tools/ab_short_k.py).
+// (OZIMMU_HIP_WIDE_GRID = g, tests: g persistent workgroups walk the tiles of ANY single product - claims, stealing and the
+// ticket drawn one tile ahead on shapes the oracle checks in a second)
 static bool wants_phase(size_t m, size_t n, size_t k, size_t batch) {
-  return batch == 1 && !config().no_phase_hint && m * n >= (size_t)2560 * 1024 && k >= 1024;
+  if (batch != 1 || config().no_phase_hint) return false;
+  return (m * n >= (size_t)2560 * 1024 && k >= 1024) || config().wide_grid > 0;
 }
 
 // Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
@@ -477,13 +480,13 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   const bool resident = !have_row_max && resident_split(k);
   const bool zero_in_row_max = use_phase && !have_row_max && (resident || !one_pass_split(8 * (m + n) * k * bs.count));
   uint32_t *const zp = zero_in_row_max ? w.phase : nullptr;
-  const uint32_t zw = (uint32_t)topology().xcds * PHASE_LINE_WORDS;
+  const uint32_t zw = (uint32_t)topology(h->device).xcds * PHASE_LINE_WORDS;
   if (use_phase && !zero_in_row_max && !zero_phase_lines(h, w.phase)) return 3;
   if (resident) {
     // one read, both operands (and every matrix of the batch) in one launch
     const SplitJob jobs[2] = {{view_A(op_A, m, k, a, lda), w.planes_a, w.ea, bs.stride_a, nullptr},
                               {view_B(op_B, k, n, b, ldb), w.planes_b, w.eb, bs.stride_b, nullptr}};
-    if (!hip_ok(launch_split_resident(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot, zp, zw, topology().cus), "split"))
+    if (!hip_ok(launch_split_resident(jobs, 2, S, L, h->stream, (uint32_t)bs.count, slot, zp, zw, topology(h->device).cus), "split"))
       return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3; // split_A + split_B -> split_A
   } else if (one_pass_split(8 * (m + n) * k * bs.count)) {
@@ -510,6 +513,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   if (prof && !hip_ok(hipEventRecord(h->ev[2], h->stream), "event")) return 3;
 
   SliceGemmArgs g{};
+  g.device = h->device;
   g.a_planes = w.planes_a;
   g.b_planes = w.planes_b;
   g.KB = (uint32_t)k_blocks(k);
@@ -641,7 +645,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
                               {view_B_part(op_B, k, n, b, ldb, 0), w.planes_b[0], w.eb[0], bb.in_stride, nullptr},
                               {view_B_part(op_B, k, n, b, ldb, 1), w.planes_b[1], w.eb[1], bb.in_stride, nullptr}};
     if (!hip_ok(launch_split_resident(jobs, 4, S, L, h->stream, (uint32_t)bs.count, slot, use_phase ? w.phase : nullptr,
-                                      (uint32_t)topology().xcds * PHASE_LINE_WORDS, topology().cus), "split"))
+                                      (uint32_t)topology(h->device).xcds * PHASE_LINE_WORDS, topology(h->device).cus), "split"))
       return 3;
     if (prof && !hip_ok(hipEventRecord(h->ev[1], h->stream), "event")) return 3;
   } else if (one_pass_split(16 * (m + n) * k * bs.count)) {
@@ -685,6 +689,7 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     const int *pq = order[q];
     SliceGemmArgs &g = prod[q];
     g = SliceGemmArgs{};
+    g.device = h->device;
     g.a_planes = w.planes_a[pq[0]];
     g.b_planes = w.planes_b[pq[1]];
     g.KB = (uint32_t)k_blocks(k);
@@ -832,7 +837,7 @@ int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm) { //
   }
   for (auto &e : h->ev) hipEventCreate(&e);
   hipEventCreateWithFlags(&h->tail_ev, hipEventDisableTiming);
-  probe_topology(); // once per device: CU / XCD count, sustained MFMA time (the launch policy plans with them)
+  probe_topology(h->device); // once per device: CU / XCD count, sustained MFMA time (the launch policy plans with them)
   auto read_thr = [](const char *name) -> uint32_t { // std::stoul in the reference (throws); here: default
     const std::string s = load_env_if_defined(name, "1024");
     char *end = nullptr;
@@ -853,10 +858,7 @@ int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm) { //
 int ozimmu_hip_device_info(ozimmu_hip_handle_t h, double out[4]) {
   if (!h || !out) return 1;
   std::lock_guard<std::recursive_mutex> lock(h->mtx);
-  int cur = h->device;
-  const bool other = hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess;
-  const Topology t = topology();
-  if (other) hipSetDevice(cur);
+  const Topology t = topology(h->device);
   out[0] = t.cus;
   out[1] = t.xcds;
   out[2] = t.mfma32_us;
@@ -864,26 +866,13 @@ int ozimmu_hip_device_info(ozimmu_hip_handle_t h, double out[4]) {
   return 0;
 }
 
-int ozimmu_hip_policy_predict(ozimmu_hip_handle_t h, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
-                              double out_us[6], int *pick) {
+static int predict_with(const Topology &topo, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
+                        double out_us[6], int *pick) {
   if (!out_us || num_split < 3 || num_split > 18 || m == 0 || n == 0 || m >= ((size_t)1 << 31) || n >= ((size_t)1 << 31))
     return 1;
   const int L = bits_for_k(k);
   PassTraits t;
   if (L == 0 || !slice_gemm_traits(num_split, pass, &t)) return 1;
-  Topology topo; // no handle (tools/policy_fit.py on a box without a GPU): the nominal device, or what the caller put into the
-                 // last two entries of the parameter table (CUs, MFMA time of the device the measurements came from)
-  if (h) {
-    std::lock_guard<std::recursive_mutex> lock(h->mtx);
-    int cur = h->device;
-    const bool other = hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess;
-    topo = topology();
-    if (other) hipSetDevice(cur);
-  } else {
-    const double *p = policy_params();
-    if (p[POLICY_PARAMS - 2] > 0) topo.cus = (int)p[POLICY_PARAMS - 2];
-    if (p[POLICY_PARAMS - 1] > 0) topo.mfma32_us = p[POLICY_PARAMS - 1];
-  }
   PolicyInput in;
   in.M = (uint32_t)m;
   in.N = (uint32_t)n;
@@ -895,12 +884,60 @@ int ozimmu_hip_policy_predict(ozimmu_hip_handle_t h, int num_split, int pass, si
   return 0;
 }
 
+int ozimmu_hip_policy_predict(ozimmu_hip_handle_t h, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
+                              double out_us[6], int *pick) {
+  Topology topo; // no handle (tools/policy_fit.py on a box without a GPU): the nominal device, or what the caller put into the
+                 // last two entries of the parameter table (CUs, MFMA time of the device the measurements came from)
+  if (h) {
+    std::lock_guard<std::recursive_mutex> lock(h->mtx);
+    topo = topology(h->device); // the device the handle was created on, whatever is current now
+  } else {
+    double p[POLICY_PARAMS];
+    policy_params_get(p);
+    if (p[POLICY_PARAMS - 2] > 0) topo.cus = (int)p[POLICY_PARAMS - 2];
+    if (p[POLICY_PARAMS - 1] > 0) topo.mfma32_us = p[POLICY_PARAMS - 1];
+  }
+  return predict_with(topo, num_split, pass, m, n, k, batch, out_us, pick);
+}
+
+int ozimmu_hip_policy_predict_device(int device, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
+                                     double out_us[6], int *pick) {
+  if (device < 0 || device >= 64) return 1;
+  return predict_with(topology(device), num_split, pass, m, n, k, batch, out_us, pick);
+}
+
+int ozimmu_hip_device_topology(int device, double inout[4], int set) {
+  if (!inout) return 1;
+  Topology t;
+  if (!set) {
+    if (!topology_slot(device, &t, false)) return 1;
+    inout[0] = t.cus;
+    inout[1] = t.xcds;
+    inout[2] = t.mfma32_us;
+    inout[3] = t.mfma32_measured_us;
+    return 0;
+  }
+#ifdef OZIMMU_HIP_TEST_HOOKS
+  if (!(inout[0] >= 1 && inout[0] <= 4096 && inout[1] >= 1 && inout[1] <= MAX_XCDS && inout[2] > 0)) return 1;
+  t.cus = (int)inout[0];
+  t.xcds = (int)inout[1];
+  t.mfma32_us = inout[2];
+  t.mfma32_measured_us = inout[3];
+  t.probed = true;
+  return topology_slot(device, &t, true) ? 0 : 1;
+#else
+  return 2; // the library that ships plans with what it probed
+#endif
+}
+
 int ozimmu_hip_policy_params(double *params, int count, int set) {
   if (!params || count < 0 || count > POLICY_PARAMS) return 1;
-  double *p = policy_params();
-  for (int i = 0; i < count; i++) {
-    if (set) p[i] = params[i];
-    else params[i] = p[i];
+  if (set) {
+    policy_params_set(params, count);
+  } else {
+    double p[POLICY_PARAMS];
+    policy_params_get(p);
+    for (int i = 0; i < count; i++) params[i] = p[i];
   }
   return 0;
 }
@@ -1412,7 +1449,7 @@ int ozimmu_hip_split_int8(ozimmu_hip_handle_t h, int8_t *out_ptr, uint32_t ldo, 
   if (v.K > 0 && resident_split(v.K)) { // the same kernel choice as the GEMM path makes for this K
     const SplitJob job{v, planes, max_exp_ptr, 0, nullptr};
     ok = ok && hip_ok(launch_split_resident(&job, 1, (int)num_split, (int)bits_per_int8, h->stream, 1, 0, nullptr, 0,
-                                            topology().cus), "split");
+                                            topology(h->device).cus), "split");
   } else if (one_pass_split(8 * v.rows * v.K)) {
     const SplitJob job{v, planes, max_exp_ptr, 0, nullptr};
     ok = ok && hip_ok(launch_split_fused(&job, 1, (int)num_split, (int)bits_per_int8, h->stream), "split");

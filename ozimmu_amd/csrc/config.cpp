@@ -68,29 +68,40 @@ static Config read_config() {
 
 // By value: in the follow-the-environment mode of the tests the static copy is rewritten on every call, and a reference
 // handed out earlier (to another thread, or to an expression that calls config() twice) would see it change underneath.
+// Production (OZIMMU_HIP_ENV_PER_CALL unset): `c` is written once, before `ready`, and read without the lock ever after.
+// Follow-the-environment mode: `per_call` (its own atomic, set before `ready`) sends EVERY reader through the lock, and a
+// re-read builds the new Config in a local - with env_per_call already set - and assigns it once (a reader could see
+// the freshly parsed copy with env_per_call still false and return a torn snapshot).
 Config config() {
   static std::mutex mtx;
   static Config c;
-  static std::atomic<bool> ready{false};
+  static std::atomic<bool> ready{false}, per_call{false};
   if (!ready.load(std::memory_order_acquire)) {
     std::lock_guard<std::mutex> lock(mtx);
     if (!ready.load(std::memory_order_relaxed)) {
       c = read_config();
+      per_call.store(c.env_per_call, std::memory_order_relaxed);
       ready.store(true, std::memory_order_release);
     }
     return c;
   }
-  if (!c.env_per_call) return c; // production: written once, before `ready`
+  if (!per_call.load(std::memory_order_relaxed)) return c;
   // tests / A-B tools: follow the environment - re-read only when it changed.  setenv / unsetenv replace or move entries of
   // `environ`, so the pointers themselves are a fingerprint (~100 ns per call instead of 36 getenv calls x the dozen uses of
-  // config() per GEMM, which made the HOST the bottleneck of every sub-50-us problem the A/B tools timed).
+  // config() per GEMM, which made the HOST the bottleneck of every sub-50-us problem the A/B tools timed); the first bytes of
+  // every entry are hashed with them, so that a putenv() buffer edited in place is seen too.
   std::lock_guard<std::mutex> lock(mtx);
   static unsigned long long seen = 0;
   unsigned long long fp = 1469598103934665603ull;
-  for (char **e = environ; e && *e; e++) fp = (fp ^ (unsigned long long)(uintptr_t)*e) * 1099511628211ull;
+  for (char **e = environ; e && *e; e++) {
+    fp = (fp ^ (unsigned long long)(uintptr_t)*e) * 1099511628211ull;
+    if (std::strncmp(*e, "OZIMMU_", 7) == 0)
+      for (const char *q = *e; *q; q++) fp = (fp ^ (unsigned char)*q) * 1099511628211ull;
+  }
   if (fp != seen) {
-    c = read_config();
-    c.env_per_call = true;
+    Config fresh = read_config();
+    fresh.env_per_call = true;
+    c = fresh;
     seen = fp;
   }
   return c;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 namespace ozhip {
 
@@ -56,7 +57,16 @@ static double g_params[POLICY_PARAMS] = {
     /* cl drift, store per block      */ 0, 0.7782,
     0, 0, 0, 0.0, 0.0};
 
-double *policy_params() { return g_params; }
+static std::mutex g_params_mtx;
+void policy_params_get(double out[POLICY_PARAMS]) {
+  std::lock_guard<std::mutex> lock(g_params_mtx);
+  std::copy(g_params, g_params + POLICY_PARAMS, out);
+}
+void policy_params_set(const double *in, int count) {
+  std::lock_guard<std::mutex> lock(g_params_mtx);
+  for (int i = 0; i < count && i < POLICY_PARAMS; i++)
+    if (std::isfinite(in[i])) g_params[i] = in[i];
+}
 
 static thread_local int t_last_pick[2] = {-1, -1};
 void note_pick(int pass_index, int code) {
@@ -65,7 +75,8 @@ void note_pick(int pass_index, int code) {
 int last_pick(int pass_index) { return pass_index >= 0 && pass_index < 2 ? t_last_pick[pass_index] : -1; }
 
 Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topology &topo, const Config &cfg) {
-  const double *p = g_params;
+  double p[POLICY_PARAMS];
+  policy_params_get(p);
   Prediction r;
   for (double &x : r.us) x = -1.0;
   const uint32_t batch = in.batch > 1 ? in.batch : 1;

@@ -52,7 +52,10 @@ struct Prediction {
 
 // the fitted constants: POLICY_PARAMS doubles, see kernel_policy.cpp for their meaning
 constexpr int POLICY_PARAMS = 40;
-double *policy_params(); // the live table (tools/policy_fit.py reads and writes it through ozimmu_hip_policy_params)
+// the table is read as a snapshot and replaced as a whole under one lock (ozimmu_hip_policy_params: tools/policy_fit.py's loop
+// may replace it while another thread's handle is planning a launch)
+void policy_params_get(double out[POLICY_PARAMS]);
+void policy_params_set(const double *in, int count); // the first `count` entries; non-finite values are ignored
 
 Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topology &topo, const Config &cfg);
 

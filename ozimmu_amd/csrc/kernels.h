@@ -55,6 +55,9 @@ struct SliceGemmArgs {
   uint32_t batch;
   size_t ws_stride;
   long long c_stride;
+  // host side only: the device of the handle this launch belongs to - the launch policy plans with ITS topology (topology.h)
+  // and the per-device kernel attributes are set for IT, never for "the current device"
+  int device;
 };
 
 // a batch of equally shaped operands: matrix b reads its input in_stride doubles after matrix 0 and writes into the

@@ -102,7 +102,7 @@ bool slice_gemm_traits(int S, int pass, PassTraits *out) {
 hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g_in, int count, hipStream_t stream) {
   if (count < 1 || count > 4) return hipErrorNotSupported;
   SliceGemmArgs g[4];
-  const uint32_t nx = (uint32_t)topology().xcds;
+  const uint32_t nx = (uint32_t)topology(g_in[0].device).xcds;
   for (int i = 0; i < count; i++) {
     g[i] = g_in[i];
     g[i].nxcd = nx;
@@ -117,7 +117,7 @@ hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g_in, int count, 
 
 hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a_in, hipStream_t stream) {
   SliceGemmArgs a = a_in;
-  a.nxcd = (uint32_t)topology().xcds; // the kernels' tile partition and per-XCD lines follow the device (topology.h)
+  a.nxcd = (uint32_t)topology(a.device).xcds; // the kernels' tile partition and per-XCD lines follow the device (topology.h)
   a.phase_min_kb = (uint32_t)config().phase_min_kb;
   a.spec_claim_kb = (uint32_t)config().spec_claim_kb;
   if (S >= 3 && S <= 6) return launch_slice_gemm_s3_6(S, a, stream);

@@ -20,10 +20,9 @@ namespace ozhip {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one bit per device id and kernel
 // instantiation (a process may drive several GPUs through one copy of this library).
+// (`dev`: SliceGemmArgs::device, the handle's device - current for the duration of the call, api.cpp: WorkspaceUse)
 template <class K>
-static hipError_t allow_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+static hipError_t allow_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t> &done, int dev) {
   const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
   if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -31,7 +30,7 @@ static hipError_t allow_dynamic_lds(K kernel, size_t bytes, std::atomic<uint64_t
   return e;
 }
 
-static int cu_count() { return topology().cus; } // CUs of the current device (probed once: topology.h)
+static int cu_count(const SliceGemmArgs &a) { return topology(a.device).cus; } // CUs of the launch's device (probed once: topology.h)
 
 // ---- classic kernel: 64x64 (or 128x64) workgroups, two waves per SIMD ----------------------------------------------
 template <int S, int D0, int ND, int FORCE_WM = 0>
@@ -51,7 +50,7 @@ static hipError_t launch_one(const SliceGemmArgs &a0, hipStream_t stream) {
   a.tiles_m = (a.M + 32 * WM - 1) / (32 * WM);
   a.tiles_n = (a.N + 63) / 64;
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = allow_dynamic_lds(slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>, lds, attr_done)) return e;
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>, lds, attr_done, a.device)) return e;
   const uint32_t nb = a.tiles_m * a.tiles_n;
   hipLaunchKernelGGL((slice_gemm_kernel<S, D0, ND, VAR_PRODUCTION, WM>), dim3(nb, a.batch > 1 ? a.batch : 1),
                      dim3(128 * WM), lds, stream, a);
@@ -66,7 +65,7 @@ static hipError_t launch_k2(const SliceGemmArgs &a0, hipStream_t stream) {
   a.tiles_m = (a.M + 63) / 64;
   a.tiles_n = (a.N + 63) / 64;
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = allow_dynamic_lds(slice_gemm_k2_kernel<S, D0, ND>, Cfg::LDS, attr_done)) return e;
+  if (hipError_t e = allow_dynamic_lds(slice_gemm_k2_kernel<S, D0, ND>, Cfg::LDS, attr_done, a.device)) return e;
   hipLaunchKernelGGL((slice_gemm_k2_kernel<S, D0, ND>), dim3(a.tiles_m * a.tiles_n, a.batch > 1 ? a.batch : 1), dim3(512),
                      Cfg::LDS, stream, a);
   return hipGetLastError();
@@ -87,7 +86,7 @@ static hipError_t launch_k2_fused(const SliceGemmArgs *g, int count, hipStream_t
       m.g[i].tiles_n = (g[i].N + 63) / 64;
     }
     static std::atomic<uint64_t> attr_done{0};
-    if (hipError_t err = allow_dynamic_lds(slice_gemm_k2_fused_kernel<S, 0, S>, Cfg::LDS, attr_done)) return err;
+    if (hipError_t err = allow_dynamic_lds(slice_gemm_k2_fused_kernel<S, 0, S>, Cfg::LDS, attr_done, a0.device)) return err;
     hipLaunchKernelGGL((slice_gemm_k2_fused_kernel<S, 0, S>), dim3(m.g[0].tiles_m * m.g[0].tiles_n, a0.batch > 1 ? a0.batch : 1),
                        dim3(512), Cfg::LDS, stream, m);
     return hipGetLastError();
@@ -161,11 +160,11 @@ static uint32_t wide_grid(SliceGemmArgs &a, const WidePlan &pl) {
   // dispatcher hands the workgroups out in order - saves every tile the round trips of its claim: +1.1 ... 1.4 % at 2 tiles
   // per CU, +0.5 % at 8 and 18; from 32 per CU on the persistent workgroups win (8192^3 +0.7 %, 16384^2 x 1024 +2.2 %: the
   // claimed order keeps an XCD's workgroups on neighbouring panels).  profiles/r4_ablate/r4r_static_grid_vs_queue_ab.txt
-  const uint32_t cus = (uint32_t)cu_count();
+  const uint32_t cus = (uint32_t)cu_count(a);
   const bool exact_few_rounds = nb % cus == 0 && nb / cus <= (uint32_t)std::max(0, config().static_rounds) && config().wide_grid == 0;
   if (a.phase && a.batch <= 1 && a.qslot < max_slots && nb > cus && !config().wide_static && !exact_few_rounds) {
     a.queue = a.phase + 16 + 2 * a.qslot;
-    nb = (uint32_t)cu_count();
+    nb = (uint32_t)cu_count(a);
     if (config().wide_grid > 0) nb = (uint32_t)config().wide_grid; // tests: few workgroups, many tiles each
   } else if (config().wide_grid > 0 && a.phase && a.batch <= 1 && a.qslot < max_slots) {
     a.queue = a.phase + 16 + 2 * a.qslot;
@@ -207,7 +206,7 @@ static hipError_t launch_wide_kernel(const SliceGemmArgs &a0, const WidePlan &pl
   SliceGemmArgs a = a0;
   const uint32_t nb = wide_grid(a, pl);
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = allow_dynamic_lds(kernel, lds, attr_done)) return e;
+  if (hipError_t e = allow_dynamic_lds(kernel, lds, attr_done, a.device)) return e;
   hipLaunchKernelGGL(kernel, dim3(nb, a.batch > 1 ? a.batch : 1), dim3(256), lds, stream, a);
   return hipGetLastError();
 }
@@ -232,7 +231,7 @@ static hipError_t launch_wide(const SliceGemmArgs &a0, const WidePlan &pl, hipSt
   SliceGemmArgs a = a0;
   const uint32_t nb = wide_grid(a, pl);
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = allow_dynamic_lds(kernel, lds, attr_done)) return e;
+  if (hipError_t e = allow_dynamic_lds(kernel, lds, attr_done, a.device)) return e;
   hipLaunchKernelGGL(kernel, dim3(nb, a.batch > 1 ? a.batch : 1), dim3(256), lds, stream, a);
   return hipGetLastError();
 }
@@ -255,7 +254,7 @@ static hipError_t launch_wide_multi_impl(const SliceGemmArgs *g, int count, cons
     nb = wide_grid(m.g[i], pl);
   }
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = allow_dynamic_lds(kernel, lds, attr_done)) return e;
+  if (hipError_t e = allow_dynamic_lds(kernel, lds, attr_done, g[0].device)) return e;
   hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), lds, stream, m);
   return hipGetLastError();
 }
@@ -277,7 +276,7 @@ static hipError_t launch_wide_multi_k64(const SliceGemmArgs *g, int count, const
     nb = wide_grid(m.g[i], pl);
   }
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = allow_dynamic_lds(kernel, LDSK, attr_done)) return e;
+  if (hipError_t e = allow_dynamic_lds(kernel, LDSK, attr_done, g[0].device)) return e;
   hipLaunchKernelGGL(kernel, dim3(nb), dim3(256), LDSK, stream, m);
   return hipGetLastError();
 }
@@ -326,7 +325,7 @@ static Pick pick_kernel(const SliceGemmArgs &a, WidePlan &pl, bool &breg, bool &
   in.N = a.N;
   in.nkb = a.kb1 - a.kb0;
   in.batch = a.batch > 1 ? a.batch : 1;
-  const Prediction r = policy_predict(t, in, topology(), config());
+  const Prediction r = policy_predict(t, in, topology(a.device), config());
   pl = r.plan[r.breg ? 5 : (int)r.pick];
   breg = r.breg;
   wm4 = r.classic_wm4;
@@ -387,7 +386,7 @@ static hipError_t launch_fused(const SliceGemmArgs *g, int count, hipStream_t st
       // 2048^3 -5 % time, 4096^3 -1..2 %); beyond that they do not, and the CUs of an XCD drift over four different panel
       // pairs in its L2 (8192^3: +1..2 % time): large products keep one launch each.
       const uint64_t tiles = (uint64_t)(pl.n_big + pl.n_small) * ((a0.N + 127) / 128);
-      const bool few_tiles = tiles <= 8ull * (uint64_t)cu_count() || config().wide_grid > 0;
+      const bool few_tiles = tiles <= 8ull * (uint64_t)cu_count(a0) || config().wide_grid > 0;
       if constexpr (K64Cfg<S>::ok) {
         if (pick == Pick::WIDE_K64 && a0.batch <= 1 && a0.phase && few_tiles) return launch_wide_multi_k64<S>(g, count, pl, breg, stream);
       }

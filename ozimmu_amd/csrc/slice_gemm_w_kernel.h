@@ -537,11 +537,11 @@ __device__ __forceinline__ void band_order(uint32_t lid, uint32_t rows, uint32_t
 template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0, int DMAE, int TAIL_, bool MULTI>
 __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int count, char *smem) {
   const SliceGemmArgs &p = g[0];
-  auto tile = [&](auto wa_tag, uint32_t rb0, uint32_t c, uint32_t xcd) {
+  auto tile = [&](auto wa_tag, uint32_t rb0, uint32_t c, uint32_t xcd, auto &&hook) {
     constexpr int W = decltype(wa_tag)::value;
     auto one = [&](const SliceGemmArgs &q) {
       if constexpr ((VARW & VARW_K64) != 0)
-        y_tile<S, D0, ND, W, VARW & ~VARW_K64, STAG, DMA0, DMAE, TAIL_>(q, smem, rb0, c, xcd);
+        y_tile<S, D0, ND, W, VARW & ~VARW_K64, STAG, DMA0, DMAE, TAIL_, OZ_Y_RING>(q, smem, rb0, c, xcd, hook);
       else if constexpr ((VARW & VARW_X16) != 0)
         x_tile<S, D0, ND, W, VARW & ~VARW_X16, STAG, DMA0, DMAE, TAIL_>(q, smem, rb0, c, xcd);
       else
@@ -575,6 +575,23 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
                              (VARW & (VARW_TRACE | VARW_NO_GLOBAL | VARW_MFMA_ONLY)) == 0;
   uint32_t spec_region = 0, spec_from = 0, spec_len = 0, spec_start = 0, spec_t = 0; // meaningful in thread 0 only
   uint32_t *spec_cnt = nullptr;
+  // The ticket of the NEXT tile is drawn inside the current tile's prologue (y_tile: prologue_hook), between the issue of the
+  // first stage's copies and the wait for them, and the SAME asm statement waits for it: the fetch-add's round trip overlaps
+  // the copies' latency, which the wave waits out anyway, and the compiler only ever sees a register whose value has arrived.
+  // (Round 4 issued the atomic at the tile boundary and waited for it one tile later: between the two the destination VGPR was
+  // in flight while the compiler believed it defined - a copy or a spill inside that window would have captured a stale
+  // ticket; ADVICE r4.  tests/test_isa_invariants.py: every returning atomic of these kernels is followed by its wait.)
+  auto draw_ticket = [&]() {
+    if constexpr (SPECULATE) {
+      if (threadIdx.x == 0 && spec_region) {
+        const uint32_t one = 1u;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(spec_t)
+                     : "v"(spec_cnt), "v"(one)
+                     : "memory");
+      }
+    }
+  };
   for (;;) {
     uint32_t kind = 0, lid = 0; // 1: big tile `lid` of its region, 2: small tile, 0: nothing left
     if (!p.queue) {
@@ -592,8 +609,7 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
       if (threadIdx.x == 0) {
         uint32_t k = 0, l = 0;
         if constexpr (SPECULATE) {
-          if (spec_region) { // the ticket drawn at the start of the previous tile (below): long back by now
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(spec_t));
+          if (spec_region) { // the ticket drawn in the previous tile's prologue (draw_ticket)
             if (spec_t < spec_len) {
               k = spec_region;
               l = spec_start + spec_t;
@@ -624,17 +640,12 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
         reinterpret_cast<volatile uint32_t *>(smem)[1] = l;
         if constexpr (SPECULATE) {
           // Short k loops (K <= 2048): a tile lasts tens of microseconds and the ~2 us round trips of its claim (a device-scope
-          // load and a fetch-add, nothing else running on the CU) are a few percent of it.  Draw the NEXT tile's ticket now,
-          // from the counter this tile came from, and look at the result at the next boundary: its round trip hides under
-          // the whole k loop (the asm statement returns at once; the tile's own vmcnt(0) waits cover it).  A ticket beyond
-          // the run's end is harmless (readers compare with >=); the full claim above then looks elsewhere.  At most one tile
-          // per workgroup is held early, so the stealing granularity suffers by less than one short tile at the kernel's end.
-          spec_region = 0;
-          if (k && spec_from == k && p.kb1 - p.kb0 <= p.spec_claim_kb) {
-            spec_region = k;
-            const uint32_t one = 1u;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(spec_t) : "v"(spec_cnt), "v"(one) : "memory");
-          }
+          // load and a fetch-add, nothing else running on the CU) are a few percent of it.  The NEXT tile's ticket is drawn
+          // from the counter this tile came from during this tile's prologue (draw_ticket above) and looked at at the next
+          // boundary.  A ticket beyond the run's end is harmless (readers compare with >=); the full claim above then looks
+          // elsewhere.  At most one tile per workgroup is held early, so the stealing granularity suffers by less than one
+          // short tile at the kernel's end.
+          spec_region = (k && spec_from == k && p.kb1 - p.kb0 <= p.spec_claim_kb) ? k : 0u;
         }
       }
       __syncthreads();
@@ -648,13 +659,13 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
       band_order<BH>(lid, p.tiles_m, p.tiles_n, r, c);
       r = __builtin_amdgcn_readfirstlane(r); // wave-uniform by construction; say so (the copies take SGPR operands)
       c = __builtin_amdgcn_readfirstlane(c);
-      tile(std::integral_constant<int, WA>{}, WA * r, c, xcd);
+      tile(std::integral_constant<int, WA>{}, WA * r, c, xcd, draw_ticket);
     } else {
       if constexpr (WA > 1) {
         band_order<BH>(lid, p.tiles_m2, p.tiles_n, r, c);
         r = __builtin_amdgcn_readfirstlane(r);
         c = __builtin_amdgcn_readfirstlane(c);
-        tile(std::integral_constant<int, WA - 1>{}, WA * p.tiles_m + (WA - 1) * r, c, xcd);
+        tile(std::integral_constant<int, WA - 1>{}, WA * p.tiles_m + (WA - 1) * r, c, xcd, draw_ticket);
       }
     }
     if (!p.queue) break;

@@ -73,9 +73,14 @@ inline constexpr YSched<S, WA> kYSched{};
 #ifndef OZ_Y_RING
 #define OZ_Y_RING 4 // A fragment ring entries (tools/gemm_ablate.hip -DOZ_Y_RING=n: A/B)
 #endif
-template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0_, int DMAE_, int TAIL_, int RING = OZ_Y_RING>
+// `prologue_hook()` runs between the issue of the first stage's copies and the wait for them: whatever round trip it makes
+// (w_persistent: the NEXT tile's claim ticket) hides under the latency this tile waits out anyway.
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0_, int DMAE_, int TAIL_, int RING = OZ_Y_RING, class HOOK = NoHook>
 __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const uint32_t rb0, const uint32_t tn,
-                                       const uint32_t xcd) {
+                                       const uint32_t xcd, HOOK &&prologue_hook = HOOK()) {
   static_assert(D0 == 0 && ND <= S, "k64 tile: the diagonals 0 .. ND-1 (single pass, or the first pass of a two-pass mode)");
 #define YC (kYSched<ND, WA>)
   constexpr int SL = ND, MA = YC.MA, KSL = 2 * SL; // staged slices; staged blocks per row-block and step
@@ -254,6 +259,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     static_for<NDMA>([&](auto cc) { copy_n(cc, 0, 0, k_issue, std::integral_constant<int, 0>{}); });
     k_issue = koff_next(k_issue);
   }
+  prologue_hook();
   if constexpr (!NO_GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (!MFMA_ONLY) {
     __builtin_amdgcn_s_barrier();

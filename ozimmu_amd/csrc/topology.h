@@ -17,9 +17,15 @@ struct Topology {
   bool probed = false;
 };
 
-// topology of the current device (defaults until probe_topology() has run for it)
-Topology topology();
-// probe the current device if that has not happened yet (device allocations + synchronisation: handle creation only)
-void probe_topology();
+// Topology of device `device` (defaults until probe_topology() has run for it).  The id is the one the HANDLE was created on
+// (handle.h: ozimmu_hip_handle::device) and travels with every launch (kernels.h: SliceGemmArgs::device): nothing on the launch
+// path asks the runtime which device happens to be current (a process that drives several GPUs plans every call for the part
+// the call runs on, whatever another thread has selected meanwhile).
+Topology topology(int device);
+// probe `device` if that has not happened yet; it must be the calling thread's current device (device allocations +
+// synchronisation: handle creation only)
+void probe_topology(int device);
+// the slot of `device` as it stands / replaced (tests: fake devices on a box without a GPU; tools)
+bool topology_slot(int device, Topology *inout, bool set);
 
 } // namespace ozhip

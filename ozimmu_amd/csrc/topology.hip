@@ -45,27 +45,29 @@ __global__ __launch_bounds__(256) void mfma_calibration_kernel(int iters, int *s
 static std::mutex g_mtx;
 static Topology g_topo[64];
 
-static int current_device() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-  return dev;
-}
+static bool valid(int dev) { return dev >= 0 && dev < 64; }
 
-Topology topology() {
-  const int dev = current_device();
+Topology topology(int device) {
   Topology t;
-  if (dev >= 0) {
+  if (valid(device)) {
     std::lock_guard<std::mutex> lock(g_mtx);
-    t = g_topo[dev];
+    t = g_topo[device];
   }
   const int forced = config().xcds;
   if (forced > 0) t.xcds = std::min(forced, 16);
   return t;
 }
 
-void probe_topology() {
-  const int dev = current_device();
-  if (dev < 0) return;
+bool topology_slot(int device, Topology *inout, bool set) {
+  if (!valid(device) || !inout) return false;
+  std::lock_guard<std::mutex> lock(g_mtx);
+  if (set) g_topo[device] = *inout;
+  else *inout = g_topo[device];
+  return true;
+}
+
+void probe_topology(int dev) {
+  if (!valid(dev)) return;
   {
     std::lock_guard<std::mutex> lock(g_mtx);
     if (g_topo[dev].probed) return;

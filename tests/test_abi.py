@@ -249,3 +249,66 @@ def test_kernel_choice_cost_model_is_host_arithmetic(lib):
     finally:
         ozimmu_amd.policy_params(p0)
     assert ozimmu_amd.policy_params() == p0
+
+
+def test_every_pick_has_a_forced_gpu_arm(lib, monkeypatch):
+    """tests/test_gpu_forced_kernels.py forces every kernel the policy can pick (kernel_policy.h: Pick + the k64 register form)
+    against the oracle.  Here, without a GPU: every name the library can report has an arm, and every arm's switches make the
+    cost model (host arithmetic) pick exactly that kernel on every shape / mode the GPU tests run it on - a kernel added to the
+    policy without a forced parity test, or an arm that silently falls back to another kernel, fails this test."""
+    import importlib
+    F = importlib.import_module("tests.test_gpu_forced_kernels")
+    names = {v for v in ozimmu_amd.KERNEL_NAMES.values() if v}
+    assert names == set(F.FORCED_ARMS) == set(F.ARM_MODES)
+    # the C++ enum behind the names: one name per Pick value + the register form
+    src = open(os.path.join(ROOT, "ozimmu_amd", "csrc", "kernel_policy.h")).read()
+    picks = re.search(r"enum class Pick \{([^}]*)\}", src).group(1)
+    assert len(re.findall(r"\w+\s*=\s*\d+", picks)) + 1 == len(names)
+    monkeypatch.setenv("OZIMMU_HIP_ENV_PER_CALL", "1")
+    for arm, S in F._arm_cases():
+        for k in ("OZIMMU_HIP_GEMM_KERNEL", "OZIMMU_HIP_PAIRED_TILE", "OZIMMU_HIP_K64_BREG", "OZIMMU_HIP_K64_TILE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in F.FORCED_ARMS[arm].items():
+            monkeypatch.setenv(k, v)
+        for m, n, k in F.SHAPES + [(1024, 1024, 1024), (700, 520, 128), (333, 900, 256), (2048, 1536, 1024)]:
+            if arm == "k2" and m * n > 256 * 4096 and (m, n, k) not in F.SHAPES:
+                continue
+            _, pick = ozimmu_amd.policy_predict(None, S, m, n, k)
+            assert pick == arm, (arm, S, m, n, k, pick)
+
+
+def test_launch_policy_is_bound_to_the_handles_device_id(lib):
+    """csrc/topology.h: the topology a launch plans with is the slot of the device its handle was created on
+    (SliceGemmArgs::device), not whatever device is current.  Two fake devices (test flavour: the slots can be set) with
+    different CU / XCD counts give different plans for the same product, each independent of the other slot and of the calling
+    thread's current device (there is none on this box); the library that ships refuses to have its slots set."""
+    T = ozimmu_amd.test_flavour().lib()
+    P = ozimmu_amd.lib()
+    for L in (T, P):
+        L.ozimmu_hip_device_topology.restype = ctypes.c_int
+        L.ozimmu_hip_device_topology.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+        L.ozimmu_hip_policy_predict_device.restype = ctypes.c_int
+        L.ozimmu_hip_policy_predict_device.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
+                                                       ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double),
+                                                       ctypes.POINTER(ctypes.c_int)]
+    v = (ctypes.c_double * 4)(64, 2, 0.0194, 0)
+    assert P.ozimmu_hip_device_topology(1, v, 1) == 2                       # product: read-only
+    assert T.ozimmu_hip_device_topology(5, (ctypes.c_double * 4)(256, 8, 0.0194, 0), 1) == 0
+    assert T.ozimmu_hip_device_topology(6, v, 1) == 0
+    assert T.ozimmu_hip_device_topology(64, v, 1) == 1 and T.ozimmu_hip_device_topology(-1, v, 0) == 1
+    got = (ctypes.c_double * 4)()
+    assert T.ozimmu_hip_device_topology(6, got, 0) == 0 and list(got)[:2] == [64.0, 2.0]
+    assert T.ozimmu_hip_device_topology(5, got, 0) == 0 and list(got)[:2] == [256.0, 8.0]
+
+    def predict(dev):
+        out, pick = (ctypes.c_double * 6)(), ctypes.c_int(-1)
+        assert T.ozimmu_hip_policy_predict_device(dev, 9, 0, 4096, 4096, 4096, 1, out, ctypes.byref(pick)) == 0
+        return list(out), pick.value
+    big, small = predict(5), predict(6)
+    best = lambda r: min(x for x in r[0] if x >= 0)
+    assert 3.0 < best(small) / best(big) < 5.0                               # a quarter of the CUs: about four times as long
+    assert predict(5) == big                                                 # ... and slot 6 did not leak into slot 5
+    # 1024^3: 256 tiles of 64 x 64 fit the 256-CU device's K-split kernel (one tile per CU) and not the 64-CU one's
+    out, pick = (ctypes.c_double * 6)(), ctypes.c_int(-1)
+    assert T.ozimmu_hip_policy_predict_device(5, 9, 0, 1024, 1024, 1024, 1, out, ctypes.byref(pick)) == 0 and out[0] >= 0
+    assert T.ozimmu_hip_policy_predict_device(6, 9, 0, 1024, 1024, 1024, 1, out, ctypes.byref(pick)) == 0 and out[0] < 0

@@ -64,10 +64,15 @@ def zbits(x):
     return np.stack([np.ascontiguousarray(x.real).view(np.uint64), np.ascontiguousarray(x.imag).view(np.uint64)])
 
 
-@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+# OZIMMU_OP_C: computed as the conjugate transpose (the reference's hook maps CUBLAS_OP_C to op_t, src/cublas.cu:50-56; DESIGN.md 2
+# deviation 10) - every combination with N / T / C, through the one-launch form of the four real products and through four launches
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T"), ("C", "N"), ("N", "C"), ("C", "C"),
+                                       ("C", "T"), ("T", "C")])
 @pytest.mark.parametrize("m,n,k,S", [(64, 64, 64, 6), (1, 1, 1, 9), (70, 33, 129, 9), (130, 65, 257, 13)])
-def test_zgemm_bit_exact_vs_oracle(oz, op_a, op_b, m, n, k, S):
+def test_zgemm_bit_exact_vs_oracle(oz, monkeypatch, op_a, op_b, m, n, k, S, fused):
     m_, h = oz
+    monkeypatch.setenv("OZIMMU_HIP_FUSED_PRODUCTS", fused)
     rng = np.random.default_rng(m + n + k + S)
     a = zoperand(op_a, m, k, rng, "wide", pad=1)
     b = zoperand(op_b, k, n, rng, "wide", pad=2)
@@ -84,6 +89,7 @@ def test_zgemm_bit_exact_vs_oracle(oz, op_a, op_b, m, n, k, S):
     assert O.zgemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
     got = np.array(c.download())
     np.testing.assert_array_equal(zbits(got), zbits(c_ref.view))
+    assert np.isnan(c.buf[:, m:]).all()  # ld padding untouched
     # ... and it IS the conjugate transpose: against numpy on the same data
     opm = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
     want = alpha * (opm[op_a](a.view) @ opm[op_b](b.view)) + beta * c0
@@ -108,6 +114,56 @@ def test_zgemm_k_at_the_pass_boundary(oz):
     kchunk = (2147483647 // (S * 127 * 127)) // 64 * 64
     assert O.zgemm("N", "T", m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL, kchunk=kchunk) == 0
     np.testing.assert_array_equal(zbits(c.download()), zbits(c_ref.view))
+
+
+@pytest.mark.parametrize("op_a,op_b", [("C", "N"), ("N", "C"), ("C", "C")])
+def test_zgemm_conjugate_transpose_across_k_passes(oz, op_a, op_b):
+    """OP_C with two chained K passes per real product (S = 6, K = 22176: 694 k-blocks against a pass length of 692): the sign
+    flip of the conjugated operand's imaginary products is applied in every pass"""
+    m_, h = oz
+    m, n, k, S = 24, 40, 22176, 6
+    rng = np.random.default_rng(k + ord(op_a) + 2 * ord(op_b))
+    a = zoperand(op_a, m, k, rng)
+    b = zoperand(op_b, k, n, rng)
+    c = zoperand("N", m, n, rng)
+    c_ref = ColMajor(m, n, dtype=np.complex128)
+    c_ref.buf[...] = c.buf
+    alpha, beta = 0.5 + 1.5j, 1.0 - 0.25j
+    assert m_.gemm(h, op_a, op_b, m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, "fp64_int8_6", m_.complx) == 0
+    _sync()
+    kchunk = (2147483647 // (S * 127 * 127)) // 64 * 64
+    assert O.zgemm(op_a, op_b, m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL, kchunk=kchunk) == 0
+    np.testing.assert_array_equal(zbits(c.download()), zbits(c_ref.view))
+
+
+@pytest.mark.parametrize("op_a,op_b", [("C", "N"), ("N", "C"), ("C", "C"), ("T", "C")])
+def test_zgemm_strided_batched_conjugate_transpose(oz, op_a, op_b):
+    """a strided batch with OP_C: every matrix bit-identical to the oracle's zgemm and to numpy's conjugate transpose"""
+    import torch
+    m_, h = oz
+    m, n, k, S, batch = 70, 66, 100, 9, 3
+    rng = np.random.default_rng(17 + ord(op_a) + 2 * ord(op_b))
+    ra, ca = (m, k) if op_a == "N" else (k, m)
+    rb, cb_ = (k, n) if op_b == "N" else (n, k)
+    A = [zoperand("N", ra, ca, rng) for _ in range(batch)]      # storage as given (op applied by the call)
+    B = [zoperand("N", rb, cb_, rng) for _ in range(batch)]
+    C0 = [zoperand("N", m, n, rng) for _ in range(batch)]
+    a = torch.from_numpy(np.stack([x.buf for x in A])).cuda()    # (batch, cols, ld) = column-major matrices back to back
+    b = torch.from_numpy(np.stack([x.buf for x in B])).cuda()
+    c = torch.from_numpy(np.stack([x.buf for x in C0])).cuda()
+    alpha, beta = 0.5 - 1j, 0.25 + 2j
+    assert m_.gemm_strided_batched(h, torch.cuda.current_stream(), op_a, op_b, m, n, k, alpha, a, ra, ra * ca, b, rb, rb * cb_,
+                                   beta, c, m, n * m, batch, "fp64_int8_9", m_.complx) == 0
+    _sync()
+    got = c.cpu().numpy()
+    opm = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+    for i in range(batch):
+        c_ref = ColMajor(m, n, dtype=np.complex128)
+        c_ref.buf[...] = C0[i].buf
+        assert O.zgemm(op_a, op_b, m, n, k, alpha, A[i].view, B[i].view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+        np.testing.assert_array_equal(zbits(got[i].T), zbits(c_ref.view))
+        want = alpha * (opm[op_a](A[i].view) @ opm[op_b](B[i].view)) + beta * C0[i].view
+        assert np.abs(got[i].T - want).max() / np.abs(want).max() < 1e-11
 
 
 def test_zgemm_beta_zero_does_not_read_c_and_real_alpha(oz):

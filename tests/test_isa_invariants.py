@@ -225,3 +225,43 @@ def test_named_b_registers_are_untouched_by_the_compiler(asm):
                 nxt_zero = rest.find("v_accvgpr_write")  # the next tile function starts by zero-filling its accumulators
                 assert nxt_mfma < 0 or (0 <= nxt_zero < nxt_mfma), f"{name}: compiler code touches v112+ inside a k loop: {l.strip()}"
                 inside = False             # epilogue reached: the next named load opens the next region
+
+
+def test_returning_atomics_are_waited_for_before_their_destination_is_touched(asm):
+    """The claim tickets of the persistent kernels are returning atomics (global_atomic_add ... sc0: the pre-op value lands in
+    a VGPR asynchronously).  Compiler-generated ones are tracked by the compiler; the hand-written one of the speculative claim
+    (slice_gemm_w_kernel.h: draw_ticket) is not - round 4 issued it at a tile boundary and waited a whole tile later, a window
+    in which a compiler-inserted copy or spill of the destination would have captured a stale ticket.  Now the wait
+    sits in the same asm statement.  Checked on the ISA for EVERY returning atomic of the slice-GEMM kernels: between the
+    atomic and the first wait that covers it (vmcnt(0), alone or inside a combined s_waitcnt) no instruction names its
+    destination register, and no branch leaves the window."""
+    lines = asm["slice_gemm.hip"].split("\n")
+    seen = hand = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"\s*global_atomic_\w+ (v\d+), .*\bsc0\b", l)
+        if not m:
+            continue
+        seen += 1
+        reg = m.group(1)
+        n = int(reg[1:])
+        in_asm_stmt = False
+        for j in range(i - 1, max(i - 6, 0), -1):       # the hand-written one sits inside #ASMSTART ... #ASMEND
+            if "#ASMSTART" in lines[j]:
+                in_asm_stmt = True
+                break
+            if "#ASMEND" in lines[j]:
+                break
+        hand += in_asm_stmt
+        for j in range(i + 1, min(i + 400, len(lines))):
+            t = lines[j].strip()
+            if not t or t.startswith(";") or t.startswith("#") or t.startswith("."):
+                continue
+            if re.match(r"s_waitcnt\b", t) and re.search(r"vmcnt\(0\)", t):
+                break
+            assert not re.match(r"s_(c)?branch|s_endpgm|s_setpc", t), f"line {j}: control flow before the wait for {reg}: {t}"
+            assert not re.search(rf"\b{reg}\b", t), f"line {j}: {reg} touched before its atomic returned: {t}"
+            for a, b in re.findall(r"v\[(\d+):(\d+)\]", t):
+                assert not (int(a) <= n <= int(b)), f"line {j}: {reg} (in a tuple) touched before its atomic returned: {t}"
+        else:
+            pytest.fail(f"line {i}: no vmcnt(0) wait after {l.strip()}")
+    assert seen >= 20 and hand >= 4, (seen, hand)   # every persistent kernel claims; the k64 kernels also speculate
