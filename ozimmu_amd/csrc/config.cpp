@@ -40,6 +40,7 @@ static Config read_config() {
   if (const char *e = counted_getenv("OZIMMU_HIP_PAIRED_TILE")) c.paired_tile = e[0] == '1' ? 1 : 0;
   if (const char *e = counted_getenv("OZIMMU_HIP_K64_TILE")) c.k64_tile = e[0] == '1' ? 1 : 0;
   if (const char *e = counted_getenv("OZIMMU_HIP_K64_BREG")) c.k64_breg = e[0] == '1' ? 1 : 0;
+  if (const char *e = counted_getenv("OZIMMU_HIP_SPLIT_PASS")) c.split_pass = e[0] == '1' ? 1 : 0;
   if (const char *e = counted_getenv("OZIMMU_HIP_FUSED_PRODUCTS")) c.fused_products = e[0] != '0';
   c.wide_small_rows = (int)number("OZIMMU_HIP_WIDE_SMALL_ROWS", -1);
   c.wide_static = number("OZIMMU_HIP_WIDE_STATIC", 0) != 0;

@@ -15,6 +15,7 @@ struct Config {
   enum Kernel { AUTO = 0, WIDE, CLASSIC, K2, X16, K64 } gemm_kernel = AUTO;
   int paired_tile = -1;        // OZIMMU_HIP_PAIRED_TILE: 1 / 0 force the 16x16x64 tile function on / off (-1: policy)
   int k64_tile = -1;           // OZIMMU_HIP_K64_TILE: 1 / 0 force the 64-k-step 16x16x64 tile function on / off (-1: policy)
+  int split_pass = -1;         // OZIMMU_HIP_SPLIT_PASS: 1 / 0 force / forbid the two-pass form of fp64_int8_11, 12 (9 diagonals on the k64 register kernel + the rest; -1: policy)
   int k64_breg = -1;           // OZIMMU_HIP_K64_BREG: 1 / 0 force the k64 tile's B fragments global -> VGPR / through LDS (-1: policy)
   bool fused_products = true;  // OZIMMU_HIP_FUSED_PRODUCTS=0: the real products of a small ZGEMM as separate launches
   int wide_small_rows = -1;    // OZIMMU_HIP_WIDE_SMALL_ROWS: rows of reduced-height tiles (measurement override)

@@ -55,6 +55,9 @@ struct SliceGemmArgs {
   uint32_t batch;
   size_t ws_stride;
   long long c_stride;
+  // host side only: fp64_int8_11 / 12 may run as two diagonal passes (9 + the rest: slice_gemm_launch.h) - `acc` is large enough and
+  // nothing in this call depends on the single-pass form (the test hook's dump of ONE launch, the fused ZGEMM launch)
+  int split_pass_ok;
   // host side only: the device of the handle this launch belongs to - the launch policy plans with ITS topology (topology.h)
   // and the per-device kernel attributes are set for IT, never for "the current device"
   int device;

@@ -28,8 +28,7 @@
 // Roofline: MFMA INT8 (dense 1024 MAC/clk/SIMD).  Algorithmic work per launch: P*2*M*N*K ops.
 //
 // Translation units: this file (dispatch on S, the complex beta scaling); slice_gemm_launch.h (kernel choice, tile plan,
-// launches) is instantiated for ranges of S by slice_gemm_s3_6.hip, _s7_10, _s11_13, _s14_15, _s16_16, _s17_17, _s18_18
-// (ranges balanced by compile time: a two-pass S costs three single-pass ones).
+// launches) is instantiated per compute mode by the slice_gemm_s<lo>_<hi>.hip units listed in OZ_GEMM_PARTS below.
 #include <hip/hip_runtime.h>
 
 #include "config.h"
@@ -64,38 +63,25 @@ hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, dou
   return hipGetLastError();
 }
 
-hipError_t launch_slice_gemm_s3_6(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s3_6(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
-hipError_t launch_slice_gemm_s7_10(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s7_10(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
-hipError_t launch_slice_gemm_s11_13(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s11_13(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
-hipError_t launch_slice_gemm_s14_15(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s14_15(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
-hipError_t launch_slice_gemm_s16_16(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s16_16(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
-hipError_t launch_slice_gemm_s17_17(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s17_17(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
-hipError_t launch_slice_gemm_s18_18(int S, const SliceGemmArgs &a, hipStream_t stream);
-hipError_t launch_slice_gemm_fused_s18_18(int S, const SliceGemmArgs *g, int count, hipStream_t stream);
+// the translation units of the slice GEMM: X(first S, last S, suffix) - one slice_gemm_<suffix>.hip each (ozimmu_amd/build.py:
+// GEMM_PARTS lists the same files), most of them one compute mode: the build is bound by its slowest unit, and a two-pass
+// mode instantiates three to four times the kernels of a single-pass one
+#define OZ_GEMM_PARTS(X) X(3, 4, s3_4) X(5, 6, s5_6) X(7, 7, s7_7) X(8, 8, s8_8) X(9, 9, s9_9) X(10, 10, s10_10) X(11, 11, s11_11) X(12, 12, s12_12) X(13, 13, s13_13) X(14, 14, s14_14) X(15, 15, s15_15) X(16, 16, s16_16) X(17, 17, s17_17) X(18, 18, s18_18)
 
-bool slice_gemm_traits_s3_6(int S, int pass, PassTraits *out);
-bool slice_gemm_traits_s7_10(int S, int pass, PassTraits *out);
-bool slice_gemm_traits_s11_13(int S, int pass, PassTraits *out);
-bool slice_gemm_traits_s14_15(int S, int pass, PassTraits *out);
-bool slice_gemm_traits_s16_16(int S, int pass, PassTraits *out);
-bool slice_gemm_traits_s17_17(int S, int pass, PassTraits *out);
-bool slice_gemm_traits_s18_18(int S, int pass, PassTraits *out);
+#define OZ_DECLARE_PART(LO, HI, NAME)                                                                          \
+  hipError_t launch_slice_gemm_##NAME(int S, const SliceGemmArgs &a, hipStream_t stream);                      \
+  hipError_t launch_slice_gemm_fused_##NAME(int S, const SliceGemmArgs *g, int count, hipStream_t stream);     \
+  bool slice_gemm_traits_##NAME(int S, int pass, PassTraits *out);
+OZ_GEMM_PARTS(OZ_DECLARE_PART)
+#undef OZ_DECLARE_PART
 
-// what the passes of mode S can run on (kernel_policy.h); pass 0: the single / first pass, 1: the second pass of S > 12
+// what the passes of mode S can run on (kernel_policy.h); pass 0: the single / first pass, 1: the second pass of a two-pass
+// mode; fp64_int8_11, 12 (single pass by default): 2 / 3 = the passes of their split form (slice_gemm_launch.h: launch_S)
 bool slice_gemm_traits(int S, int pass, PassTraits *out) {
-  if (S >= 3 && S <= 6) return slice_gemm_traits_s3_6(S, pass, out);
-  if (S >= 7 && S <= 10) return slice_gemm_traits_s7_10(S, pass, out);
-  if (S >= 11 && S <= 13) return slice_gemm_traits_s11_13(S, pass, out);
-  if (S >= 14 && S <= 15) return slice_gemm_traits_s14_15(S, pass, out);
-  if (S == 16) return slice_gemm_traits_s16_16(S, pass, out);
-  if (S == 17) return slice_gemm_traits_s17_17(S, pass, out);
-  if (S == 18) return slice_gemm_traits_s18_18(S, pass, out);
+#define OZ_TRAITS_PART(LO, HI, NAME) \
+  if (S >= LO && S <= HI) return slice_gemm_traits_##NAME(S, pass, out);
+  OZ_GEMM_PARTS(OZ_TRAITS_PART)
+#undef OZ_TRAITS_PART
   return false;
 }
 
@@ -109,9 +95,10 @@ hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g_in, int count, 
     g[i].phase_min_kb = (uint32_t)config().phase_min_kb;
     g[i].spec_claim_kb = (uint32_t)config().spec_claim_kb;
   }
-  if (S >= 3 && S <= 6) return launch_slice_gemm_fused_s3_6(S, g, count, stream);
-  if (S >= 7 && S <= 10) return launch_slice_gemm_fused_s7_10(S, g, count, stream);
-  if (S >= 11 && S <= 13) return launch_slice_gemm_fused_s11_13(S, g, count, stream);
+#define OZ_FUSED_PART(LO, HI, NAME) \
+  if (S >= LO && S <= HI) return launch_slice_gemm_fused_##NAME(S, g, count, stream);
+  OZ_GEMM_PARTS(OZ_FUSED_PART)
+#undef OZ_FUSED_PART
   return hipErrorNotSupported; // two diagonal passes per product
 }
 
@@ -120,13 +107,10 @@ hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a_in, hipStream_t strea
   a.nxcd = (uint32_t)topology(a.device).xcds; // the kernels' tile partition and per-XCD lines follow the device (topology.h)
   a.phase_min_kb = (uint32_t)config().phase_min_kb;
   a.spec_claim_kb = (uint32_t)config().spec_claim_kb;
-  if (S >= 3 && S <= 6) return launch_slice_gemm_s3_6(S, a, stream);
-  if (S >= 7 && S <= 10) return launch_slice_gemm_s7_10(S, a, stream);
-  if (S >= 11 && S <= 13) return launch_slice_gemm_s11_13(S, a, stream);
-  if (S >= 14 && S <= 15) return launch_slice_gemm_s14_15(S, a, stream);
-  if (S >= 16 && S <= 16) return launch_slice_gemm_s16_16(S, a, stream);
-  if (S >= 17 && S <= 17) return launch_slice_gemm_s17_17(S, a, stream);
-  if (S >= 18 && S <= 18) return launch_slice_gemm_s18_18(S, a, stream);
+#define OZ_LAUNCH_PART(LO, HI, NAME) \
+  if (S >= LO && S <= HI) return launch_slice_gemm_##NAME(S, a, stream);
+  OZ_GEMM_PARTS(OZ_LAUNCH_PART)
+#undef OZ_LAUNCH_PART
   return hipErrorInvalidValue;
 }
 

@@ -1,4 +1,4 @@
-// slice-GEMM kernels and launch policy of fp64_int8_17 .. fp64_int8_17 (see slice_gemm_launch.h, slice_gemm.hip)
+// slice-GEMM kernels and launch policy of fp64_int8_17 (see slice_gemm_launch.h, slice_gemm.hip: OZ_GEMM_PARTS)
 #define OZ_S_LO 17
 #define OZ_S_HI 17
 #define OZ_PART launch_slice_gemm_s17_17

@@ -1,0 +1,7 @@
+// slice-GEMM kernels and launch policy of fp64_int8_9 (see slice_gemm_launch.h, slice_gemm.hip: OZ_GEMM_PARTS)
+#define OZ_S_LO 9
+#define OZ_S_HI 9
+#define OZ_PART launch_slice_gemm_s9_9
+#define OZ_PART_FUSED launch_slice_gemm_fused_s9_9
+#define OZ_PART_TRAITS slice_gemm_traits_s9_9
+#include "slice_gemm_launch.h"
