@@ -116,9 +116,7 @@ static int bits_for_k(size_t k) {
 static bool needs_acc(size_t k, int S) {
   const int L = bits_for_k(k);
   if (L == 0) return false;
-  // (fp64_int8_11, 12: single pass, or 9 diagonals + the rest through the FP64 workspace - slice_gemm_launch.h: split_pass_pays -
-  // the launcher decides per launch, the workspace allows both unless OZIMMU_HIP_SPLIT_PASS=0)
-  return S > SINGLE_PASS_MAX_S || (S >= 11 && config().split_pass != 0) || k_blocks(k) > (size_t)kb_per_pass(S, L);
+  return S > SINGLE_PASS_MAX_S || k_blocks(k) > (size_t)kb_per_pass(S, L);
 }
 
 static OperandView view_A(ozimmu_operation_t op, size_t m, size_t k, const double *a, size_t lda) {
@@ -516,7 +514,6 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
 
   SliceGemmArgs g{};
   g.device = h->device;
-  g.split_pass_ok = 1;
   g.a_planes = w.planes_a;
   g.b_planes = w.planes_b;
   g.KB = (uint32_t)k_blocks(k);
@@ -693,7 +690,6 @@ static int gemm_int8_complex(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozi
     SliceGemmArgs &g = prod[q];
     g = SliceGemmArgs{};
     g.device = h->device;
-    g.split_pass_ok = 1;
     g.a_planes = w.planes_a[pq[0]];
     g.b_planes = w.planes_b[pq[1]];
     g.KB = (uint32_t)k_blocks(k);

@@ -15,7 +15,6 @@ struct Config {
   enum Kernel { AUTO = 0, WIDE, CLASSIC, K2, X16, K64 } gemm_kernel = AUTO;
   int paired_tile = -1;        // OZIMMU_HIP_PAIRED_TILE: 1 / 0 force the 16x16x64 tile function on / off (-1: policy)
   int k64_tile = -1;           // OZIMMU_HIP_K64_TILE: 1 / 0 force the 64-k-step 16x16x64 tile function on / off (-1: policy)
-  int split_pass = -1;         // OZIMMU_HIP_SPLIT_PASS: 1 / 0 force / forbid the two-pass form of fp64_int8_11, 12 (9 diagonals on the k64 register kernel + the rest; -1: policy)
   int k64_breg = -1;           // OZIMMU_HIP_K64_BREG: 1 / 0 force the k64 tile's B fragments global -> VGPR / through LDS (-1: policy)
   bool fused_products = true;  // OZIMMU_HIP_FUSED_PRODUCTS=0: the real products of a small ZGEMM as separate launches
   int wide_small_rows = -1;    // OZIMMU_HIP_WIDE_SMALL_ROWS: rows of reduced-height tiles (measurement override)
@@ -26,6 +25,7 @@ struct Config {
   bool no_exp_reuse = false;   // OZIMMU_HIP_NO_EXP_REUSE: auto mode recomputes the row maxima in the GEMM
   int phase_min_kb = 32;       // OZIMMU_HIP_PHASE_MIN_KB: passes of at most this many k-blocks run without the phase hint
   int static_rounds = 20;      // OZIMMU_HIP_STATIC_ROUNDS: up to this many EXACT rounds of tiles run as a static grid instead of persistent workgroups (0: never)
+  bool epi_overlap = true;     // OZIMMU_HIP_EPI_OVERLAP=0: the k64 register kernels keep the whole FP64 recombination behind their k loop
   int spec_claim_kb = 64;      // OZIMMU_HIP_SPEC_CLAIM_KB: k loops of at most this many k-blocks claim the next tile one tile ahead (0: never)
   bool no_phase_hint = false;  // OZIMMU_HIP_NO_PHASE_HINT
   bool batch_loop = false;     // OZIMMU_HIP_BATCH_LOOP: strided batches as a per-matrix loop

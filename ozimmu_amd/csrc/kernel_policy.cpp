@@ -74,12 +74,6 @@ void note_pick(int pass_index, int code) {
 }
 int last_pick(int pass_index) { return pass_index >= 0 && pass_index < 2 ? t_last_pick[pass_index] : -1; }
 
-double policy_acc_roundtrip_us(const PolicyInput &in) {
-  double p[POLICY_PARAMS];
-  policy_params_get(p);
-  return p[C_US_PER_MB] * 8e-6 * (double)in.M * (double)in.N * (double)(in.batch > 1 ? in.batch : 1);
-}
-
 Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topology &topo, const Config &cfg) {
   double p[POLICY_PARAMS];
   policy_params_get(p);

@@ -58,9 +58,6 @@ void policy_params_get(double out[POLICY_PARAMS]);
 void policy_params_set(const double *in, int count); // the first `count` entries; non-finite values are ignored
 
 Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topology &topo, const Config &cfg);
-// what a second diagonal pass adds beyond its own kernel: the FP64 partial sums (M x N x 8 bytes) written by the first pass
-// INSTEAD of C (already in its prediction) and read back by the second
-double policy_acc_roundtrip_us(const PolicyInput &in);
 
 // bookkeeping for diagnostics: the kernel the calling thread's last pass launched (Pick, + 8 for the k64 register form)
 void note_pick(int pass_index, int code);

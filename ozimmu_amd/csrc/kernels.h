@@ -43,6 +43,7 @@ struct SliceGemmArgs {
   uint32_t phase_min_kb; // passes of at most this many k-blocks run without the phase hint (filled in by launch_slice_gemm)
   uint32_t spec_claim_kb; // persistent k64 kernels: passes of at most this many k-blocks draw the next tile's ticket one tile ahead
                           // (slice_gemm_w_kernel.h; filled in by launch_slice_gemm; 0: never)
+  uint32_t epi_overlap; // k64 register kernels: recombine the finished row blocks in the shadow of the last step's MFMAs (filled in by launch_slice_gemm)
   uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
   // test hook, compiled only with -DOZIMMU_HIP_TEST_HOOKS (libozimmu_hip_test.so, loaded by the tests that need a hook; the
   // library that ships, libozimmu_hip.so, carries none: ozimmu_amd/build.py): INT32 diagonal sums
@@ -55,9 +56,6 @@ struct SliceGemmArgs {
   uint32_t batch;
   size_t ws_stride;
   long long c_stride;
-  // host side only: fp64_int8_11 / 12 may run as two diagonal passes (9 + the rest: slice_gemm_launch.h) - `acc` is large enough and
-  // nothing in this call depends on the single-pass form (the test hook's dump of ONE launch, the fused ZGEMM launch)
-  int split_pass_ok;
   // host side only: the device of the handle this launch belongs to - the launch policy plans with ITS topology (topology.h)
   // and the per-device kernel attributes are set for IT, never for "the current device"
   int device;

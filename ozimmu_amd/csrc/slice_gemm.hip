@@ -75,8 +75,7 @@ hipError_t launch_scale_c_complex(size_t m, size_t n, double *c, size_t ldc, dou
 OZ_GEMM_PARTS(OZ_DECLARE_PART)
 #undef OZ_DECLARE_PART
 
-// what the passes of mode S can run on (kernel_policy.h); pass 0: the single / first pass, 1: the second pass of a two-pass
-// mode; fp64_int8_11, 12 (single pass by default): 2 / 3 = the passes of their split form (slice_gemm_launch.h: launch_S)
+// what the passes of mode S can run on (kernel_policy.h); pass 0: the single / first pass, 1: the second pass of S > 12
 bool slice_gemm_traits(int S, int pass, PassTraits *out) {
 #define OZ_TRAITS_PART(LO, HI, NAME) \
   if (S >= LO && S <= HI) return slice_gemm_traits_##NAME(S, pass, out);
@@ -94,6 +93,7 @@ hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g_in, int count, 
     g[i].nxcd = nx;
     g[i].phase_min_kb = (uint32_t)config().phase_min_kb;
     g[i].spec_claim_kb = (uint32_t)config().spec_claim_kb;
+    g[i].epi_overlap = config().epi_overlap ? 1u : 0u;
   }
 #define OZ_FUSED_PART(LO, HI, NAME) \
   if (S >= LO && S <= HI) return launch_slice_gemm_fused_##NAME(S, g, count, stream);
@@ -107,6 +107,7 @@ hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a_in, hipStream_t strea
   a.nxcd = (uint32_t)topology(a.device).xcds; // the kernels' tile partition and per-XCD lines follow the device (topology.h)
   a.phase_min_kb = (uint32_t)config().phase_min_kb;
   a.spec_claim_kb = (uint32_t)config().spec_claim_kb;
+  a.epi_overlap = config().epi_overlap ? 1u : 0u;
 #define OZ_LAUNCH_PART(LO, HI, NAME) \
   if (S >= LO && S <= HI) return launch_slice_gemm_##NAME(S, a, stream);
   OZ_GEMM_PARTS(OZ_LAUNCH_PART)

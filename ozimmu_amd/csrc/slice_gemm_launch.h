@@ -397,61 +397,23 @@ static hipError_t launch_fused(const SliceGemmArgs *g, int count, hipStream_t st
   }
 }
 
-// Two diagonal ranges [0, ND1) and [ND1, S): the second pass continues the first one's fma chain through the FP64 `acc`
-// workspace (same summation order, bit-identical to a single pass).
-template <int S, int ND1>
-static hipError_t launch_two_passes(const SliceGemmArgs &a, hipStream_t stream) {
-  constexpr int ND2 = S - ND1;
-  SliceGemmArgs a1 = a;
-  a1.final = 0; // -> acc
-  hipError_t e = launch_pass<S, 0, ND1>(a1, stream);
-  if (e != hipSuccess) return e;
-  SliceGemmArgs a2 = a;
-  a2.acc_in = 1;
-  a2.qslot = a.qslot + 1; // own claim counters (the host advances qslot by 2 per call of launch_slice_gemm)
-  if (a2.dump) a2.dump += (size_t)ND1 * a.N * a.M;
-  return launch_pass<S, ND1, ND2>(a2, stream);
-}
-
-// fp64_int8_11, 12 fit one pass (352 / 384 accumulator registers on 64 x 128 tiles), but not on the kernel that runs a slice
-// product fastest: the k64 tile with its B fragments in registers holds 9 diagonals (288 accumulators + two B register sets,
-// slice_gemm_y_tile.h).  SPLIT form: the diagonals 0 .. 8 - 45 of the 66 / 78 products, staging the slices 0 .. 8 only - run on
-// that kernel, the remaining 2 / 3 diagonals (21 / 33 products over all S slices, 2 / 3 accumulators per output: the tallest
-// tiles LDS allows) in a second pass behind the FP64 workspace.  Which form runs: the cost model's sum of both passes against
-// the single pass (OZIMMU_HIP_SPLIT_PASS = 1 / 0 forces / forbids; the host offers it by handing over `acc`).
-constexpr int SPLIT_PASS_MIN_S = 11, SPLIT_PASS_ND1 = 9;
-template <int S>
-static bool split_pass_pays(const SliceGemmArgs &a) {
-  const Config cfg = config();
-  if (!a.acc || !a.split_pass_ok || cfg.split_pass == 0) return false;
-  if (cfg.split_pass == 1) return true;
-  if (cfg.forced_kernel()) return false; // a forced kernel family is a statement about the single pass (tests, A/B tools)
-  PolicyInput in;
-  in.M = a.M;
-  in.N = a.N;
-  in.nkb = a.kb1 - a.kb0;
-  in.batch = a.batch > 1 ? a.batch : 1;
-  const Topology topo = topology(a.device);
-  auto best = [&](const PassTraits &t) {
-    const Prediction r = policy_predict(t, in, topo, cfg);
-    return r.us[r.breg ? 5 : (int)r.pick];
-  };
-  const double one = best(pass_traits<S, 0, S>());
-  const double two = best(pass_traits<S, 0, SPLIT_PASS_ND1>()) + best(pass_traits<S, SPLIT_PASS_ND1, S - SPLIT_PASS_ND1>()) +
-                     policy_acc_roundtrip_us(in);
-  return two < one;
-}
-
-// S <= SINGLE_PASS_MAX_S: all S diagonals in one pass (S = 11, 12: or the split form above).  Larger S: two diagonal ranges.
+// S <= SINGLE_PASS_MAX_S: all S diagonals in one pass.  Larger S: two diagonal ranges, the second pass
+// continues the first one's fma chain through the FP64 `acc` workspace (same summation order).
 template <int S>
 static hipError_t launch_S(SliceGemmArgs a, hipStream_t stream) {
   if constexpr (S <= SINGLE_PASS_MAX_S) {
-    if constexpr (S >= SPLIT_PASS_MIN_S) {
-      if (split_pass_pays<S>(a)) return launch_two_passes<S, SPLIT_PASS_ND1>(a, stream);
-    }
     return launch_pass<S, 0, S>(a, stream);
   } else {
-    return launch_two_passes<S, (S + 1) / 2>(a, stream);
+    constexpr int ND1 = (S + 1) / 2, ND2 = S - ND1;
+    SliceGemmArgs a1 = a;
+    a1.final = 0; // -> acc
+    hipError_t e = launch_pass<S, 0, ND1>(a1, stream);
+    if (e != hipSuccess) return e;
+    SliceGemmArgs a2 = a;
+    a2.acc_in = 1;
+    a2.qslot = a.qslot + 1; // own claim counters (the host advances qslot by 2 per call of launch_slice_gemm)
+    if (a2.dump) a2.dump += (size_t)ND1 * a.N * a.M;
+    return launch_pass<S, ND1, ND2>(a2, stream);
   }
 }
 
@@ -476,16 +438,6 @@ static bool traits_S(int s, int pass, PassTraits *out) {
   } else {
     if (s != S) return traits_S<S + 1>(s, pass, out);
     if constexpr (S <= SINGLE_PASS_MAX_S) {
-      if constexpr (S >= SPLIT_PASS_MIN_S) { // 2 / 3: the passes of the split form
-        if (pass == 2) {
-          *out = pass_traits<S, 0, SPLIT_PASS_ND1>();
-          return true;
-        }
-        if (pass == 3) {
-          *out = pass_traits<S, SPLIT_PASS_ND1, S - SPLIT_PASS_ND1>();
-          return true;
-        }
-      }
       if (pass != 0) return false;
       *out = pass_traits<S, 0, S>();
     } else {

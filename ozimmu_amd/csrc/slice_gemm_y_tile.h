@@ -275,9 +275,108 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   asm volatile("s_nop 7" ::: "memory"); // zero-fill -> first MFMA reading it as C
 
   uint32_t it = 0;
+  auto acc = [&](int a, int b, int d, int v) -> int {
+    const int x = (a * 2 + b) * ND + d;
+    if (x >= 64) return accV[x >= 64 ? x - 64 : 0][v];
+    int r;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(accA[x < 64 ? x : 0][v]));
+    return r;
+  };
+
+  // ---- the epilogue in the shadow of the LAST step's MFMAs (VARW_BREG kernels) ---------------------------------------------------
+  // The tile boundary of this kernel IS the FP64 recombination (profiles/r4_ablate/r4l_tile_boundary_...: 3.8 - 4.0 us per 64 x 128
+  // tile whatever K is - 9 x (v_accvgpr_read + v_cvt_f64_i32 + v_fma_f64) per output, ~4 000 VALU cycles per wave with the matrix
+  // pipe idle; 11 % of the kernel at K = 512, 7 % at K = 1024).  A step walks the 16-row blocks a = 0 .. MA-1 one after the other,
+  // so in the last step the accumulators of block a are final once its MFMAs have issued: their recombination is cut into
+  // micro-operations (one diagonal of one column pair: 2 reads, 2 conversions, 2 fma) that are issued BETWEEN the MFMAs of block
+  // a + 1 - a wave issues VALU work while the matrix pipe works off a 16-cycle MFMA -, and only the last block's recombination is
+  // left behind the k loop.  Same operations on every element in the same order as recombine_and_store16 (its 16-byte store form):
+  // bit-identical.  Interior tiles of a real, final, single-chunk product with an even ldc and a 16-byte aligned C (what that
+  // store form asks for); every other tile takes the plain last step and the plain epilogue.  The condition is uniform over the
+  // WORKGROUP (the overlapped last step has no barrier: its waves must agree on the number of barriers they pass).
+  constexpr int EPU = ND + 3;                 // micro-operations per unit (column pair of a 16 x 16 block): begin, ND diagonals, scale, store
+  constexpr int EPB = 4 * EPU;                // ... per 16-row block: units (b, vp) = 2 column blocks x 2 column pairs
+  constexpr int SPA = NS / MA;                // MFMA slots per 16-row block
+  constexpr int EPI_T0 = 3;                   // first micro-operation this many slots into the next block (the last MFMA of the finished
+                                              // block is two slots = 32 cycles old: XDL write -> VALU read needs 11 wait states)
+  constexpr bool OVERLAP_BUILT = BREG && !NO_GLOBAL && !MFMA_ONLY && ((VARW >> 8) & 3) == 0 && (VARW & VARW_NO_EPILOGUE) == 0 &&
+                                 SPA * MA == NS && SPA >= EPB + EPI_T0 + 2;
+  const uint32_t e_mu = rb0 * 32u, e_nu = tn * 128u + (uint32_t)wave * 32u;
+  bool overlap = false;
+  if constexpr (OVERLAP_BUILT) {
+    overlap = p.epi_overlap && p.final && !p.cplx && !p.acc_in && e_mu + 16u * MA <= p.M && tn * 128u + 128u <= p.N &&
+              (p.ldc & 1u) == 0 && p.ldc < (1u << 26) && (reinterpret_cast<uintptr_t>(p.c) & 15u) == 0 && nk >= 2;
+#ifdef OZIMMU_HIP_TEST_HOOKS
+    overlap = overlap && !p.dump;
+#endif
+  }
+  double e_sc[OVERLAP_BUILT ? ND : 1], e_ea[OVERLAP_BUILT ? MA : 1], e_eb[OVERLAP_BUILT ? 8 : 1];
+  double e_x0 = 0, e_x1 = 0, e_v0 = 0, e_v1 = 0;
+  double2 e_old[OVERLAP_BUILT ? 4 : 1];
+  uint32_t e_boff = 0;
+  bool e_odd = false, e_rmw = false;
+  auto e_colp = [&](uint32_t cofs, int A) { // wave-uniform: column nu + cofs (+ nl per lane, in e_boff), first row of block A
+    return reinterpret_cast<char *>(p.c + ((size_t)(e_nu + cofs) * p.ldc + e_mu)) + 128 * A;
+  };
+  auto epi_setup = [&]() { // issued a block's worth of MFMAs ahead of the first use: exponents, the old C of block 0
+    const uint32_t nl = 4u * ((uint32_t)lane >> 4);
+    e_odd = (lane & 1) != 0;
+    e_rmw = p.beta != 0.0;
+    e_boff = ((nl + ((uint32_t)lane & 1u)) * (uint32_t)p.ldc + ((uint32_t)lane & 14u)) * 8u;
+#pragma unroll
+    for (int d = 0; d < ND; d++) e_sc[d] = pow2d(46 - p.L * (D0 + d + 2));
+#pragma unroll
+    for (int a = 0; a < MA; a++) e_ea[a] = p.ea[e_mu + ((uint32_t)lane & 15u) + 16 * a];
+    const double *eb_lane = p.eb + e_nu + nl;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) e_eb[4 * b + v] = eb_lane[16 * b + v];
+    if (e_rmw) {
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        e_old[u] = *reinterpret_cast<const double2 *>(e_colp(16 * (u >> 1) + 2 * (u & 1), 0) + (size_t)e_boff);
+    }
+  };
+  // micro-operation m of block A (compile-time indices)
+  auto epi_micro = [&](auto a_tag, auto m_tag) {
+    constexpr int A = decltype(a_tag)::value, m = decltype(m_tag)::value;
+    constexpr int u = m / EPU, q = m % EPU, b = u >> 1, vp = u & 1;
+    constexpr uint32_t cofs = 16 * b + 2 * vp;
+    if constexpr (q == 0) {
+      e_x0 = e_x1 = 0.0;
+    } else if constexpr (q <= ND) {
+      constexpr int d = q - 1;
+      e_x0 = fma((double)acc(A, b, d, 2 * vp), e_sc[d], e_x0);
+      e_x1 = fma((double)acc(A, b, d, 2 * vp + 1), e_sc[d], e_x1);
+    } else if constexpr (q == ND + 1) {
+      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
+      e_v0 = e_x0 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp];
+      e_v1 = e_x1 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp + 1];
+    } else {
+      const double s0 = lane_pair_swap(e_v0), s1 = lane_pair_swap(e_v1);
+      double2 y;
+      y.x = e_odd ? s1 : e_v0; // row 2i:     (column n from this lane | column n+1 from the even neighbour)
+      y.y = e_odd ? e_v1 : s0; // row 2i + 1: (column n from the odd neighbour | column n+1 from this lane)
+      char *cp = e_colp(cofs, A) + (size_t)e_boff;
+      if (e_rmw) {
+        y.x = fma(p.alpha, y.x, p.beta * e_old[u].x);
+        y.y = fma(p.alpha, y.y, p.beta * e_old[u].y);
+        if constexpr (A + 1 < MA) // the old values of the next block's unit u: a block's worth of MFMAs ahead of their use
+          e_old[u] = *reinterpret_cast<const double2 *>(e_colp(cofs, A + 1) + (size_t)e_boff);
+      } else {
+        y.x = p.alpha * y.x;
+        y.y = p.alpha * y.y;
+      }
+      *reinterpret_cast<double2 *>(cp) = y;
+    }
+  };
+
   // PAR (VARW_BREG): the register set this step multiplies out of; the next step's fragments are loaded into the other one
-  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag) {
-    constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value;
+  // EPI: the overlapped last step (above)
+  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag, auto epi_tag) {
+    constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value, EPI = decltype(epi_tag)::value;
+    static_assert(!EPI || (!PF && !NX), "the overlapped last step prefetches nothing and meets no barrier");
     constexpr int PC = BREG ? decltype(par_tag)::value : 0, PN = BREG ? (PC ^ 1) : 0;
     const int abuf_n = abuf ^ 1;
     const int abuf_pf = abuf_n, bbuf_pf = NB == 1 ? 0 : (bbuf ^ 1);
@@ -325,6 +424,20 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
                    g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       else
         mfma(std::integral_constant<int, X>{}, bj[b][j], g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
+      if constexpr (EPI) {
+        if constexpr (s == 1) {
+          epi_setup();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (a >= 1) { // block a - 1 is final: its micro-operations EPI_T0 .. spread over this block's slots
+          constexpr int t = s - a * SPA;
+          static_for<EPB>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (EPI_T0 + m * (SPA - EPI_T0 - 1) / EPB == t) epi_micro(std::integral_constant<int, a - 1>{}, mc);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       if constexpr (s >= XS && NX && !MFMA_ONLY) {
         if constexpr (!BREG) {
           constexpr int NREF = 2 * (SL - JT);                 // fragments refreshed behind the barrier
@@ -368,28 +481,40 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     // an even number of steps only (slice_gemm_launch.h).
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    using NO = std::false_type;
+    if constexpr (OVERLAP_BUILT) {
+      if (overlap) {
+        for (; it + 2 < nk;) {
+          step(std::true_type{}, std::true_type{}, P0{}, NO{});
+          it++;
+          step(std::true_type{}, std::true_type{}, P1{}, NO{});
+          it++;
+        }
+        step(std::true_type{}, std::true_type{}, P0{}, NO{});
+        it++;
+        step(NO{}, NO{}, P1{}, std::true_type{}); // nothing prefetched, no barrier; blocks 0 .. MA-2 recombined and stored
+        it++;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulators
+        static_for<EPB>([&](auto mc) { epi_micro(std::integral_constant<int, MA - 1>{}, mc); });
+        return;
+      }
+    }
     for (; it < nk;) {
-      step(std::true_type{}, std::true_type{}, P0{});
+      step(std::true_type{}, std::true_type{}, P0{}, NO{});
       it++;
-      step(std::true_type{}, std::true_type{}, P1{});
+      step(std::true_type{}, std::true_type{}, P1{}, NO{});
       it++;
     }
   } else {
     using P0 = std::integral_constant<int, 0>;
-    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{});
+    using NO = std::false_type;
+    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{}, NO{});
     if constexpr (PD > 1)
-      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{});
-    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{});
+      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{}, NO{});
+    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{}, NO{});
   }
 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulator
-  auto acc = [&](int a, int b, int d, int v) -> int {
-    const int x = (a * 2 + b) * ND + d;
-    if (x >= 64) return accV[x >= 64 ? x - 64 : 0][v];
-    int r;
-    asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(accA[x < 64 ? x : 0][v]));
-    return r;
-  };
   if constexpr ((VARW & VARW_NO_EPILOGUE) != 0) {
 #pragma unroll
     for (int x = 0; x < NACC_A; x++) asm volatile("" ::"a"(accA[x]));

@@ -170,82 +170,3 @@ def test_few_persistent_workgroups_walk_many_tiles(oz, monkeypatch, arm, S, m, n
     assert m_.last_kernel(h)[0] == arm
     assert O.gemm("T", "N", m, n, k, 1.5, a.view, b.view, -0.5, c_ref.view, S, O.ORDER_DIAGONAL) == 0
     np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
-
-
-# ---- fp64_int8_11 / 12: one pass, or 9 diagonals on the k64 register kernel + the rest through the FP64 workspace ---------------
-@pytest.mark.parametrize("split", [0, 1])
-@pytest.mark.parametrize("S", [11, 12])
-@pytest.mark.parametrize("m,n,k", SHAPES + [(97, 129, 65), (300, 140, 200)])
-def test_split_pass_diagonal_sums_bit_exact(ozh, monkeypatch, S, m, n, k, split):
-    import torch
-    m_, h = ozh
-    _force(monkeypatch, "k64_breg")
-    monkeypatch.delenv("OZIMMU_HIP_GEMM_KERNEL")          # the policy picks inside each pass; the register form wherever it exists
-    monkeypatch.setenv("OZIMMU_HIP_SPLIT_PASS", str(split))
-    rng = np.random.default_rng(m * 5 + n * 3 + k + S)
-    a = operand("N", m, k, rng, fill=exp_rand(2.0))
-    b = operand("T", k, n, rng, fill=exp_rand(2.0))
-    L = O.bits_per_int8(k)
-    pa, _ = O.split("A", "N", a.view, S, L)
-    pb, _ = O.split("B", "T", b.view, S, L)
-    d_ref = O.diagonal_sums(pa, pb)
-    out = torch.full((S, n, m), 12345, dtype=torch.int32, device="cuda")
-    assert m_.diagonal_sums(h, "N", "T", m, n, k, a.dev, a.ld, b.dev, b.ld, S, out) == 0
-    _sync()
-    lk = m_.last_kernel(h)
-    assert (lk[1] is not None) == bool(split), lk
-    np.testing.assert_array_equal(out.cpu().numpy().transpose(0, 2, 1).astype(np.int64), d_ref)
-
-
-@pytest.mark.parametrize("split", [0, 1])
-@pytest.mark.parametrize("S", [11, 12])
-@pytest.mark.parametrize("op_a,op_b", [("N", "N"), ("T", "T")])
-@pytest.mark.parametrize("m,n,k", SHAPES + [(389, 257, 130), (24, 40, 22176)])
-def test_split_pass_gemm_bit_exact_vs_oracle(oz, monkeypatch, S, m, n, k, op_a, op_b, split):
-    """both forms give the oracle's bits (the second pass continues the first one's fma chain: same summation order), also
-    across the K chunks of a long K (22176 at S = 11: two chunks x two passes)"""
-    m_, h = oz
-    monkeypatch.setenv("OZIMMU_HIP_SPLIT_PASS", str(split))
-    rng = np.random.default_rng(m + 2 * n + 3 * k + S)
-    a = operand(op_a, m, k, rng, pad=1)
-    b = operand(op_b, k, n, rng, pad=2)
-    c = ColMajor(m, n, ld=m + 3, fill=uniform_pm1, rng=rng)
-    c_ref = ColMajor(m, n, ld=m + 3)
-    c_ref.buf[...] = c.buf
-    st = m_.gemm(h, op_a, op_b, m, n, k, -0.75, a.dev, a.ld, b.dev, b.ld, 1.25, c.dev, c.ld, f"fp64_int8_{S}")
-    _sync()
-    assert st == 0
-    lk = m_.last_kernel(h)
-    assert (lk[1] is not None) == bool(split), lk
-    kb = (k + 31) // 32
-    kb += kb & 1 if kb > 32 else 0                      # layout.h: k_blocks - odd counts beyond 32 are padded to even
-    if split and kb % 4 == 0 and k < 14000:
-        assert lk[0] == "k64_breg", lk                  # 45 of the 66 / 78 products on the register kernel
-    L = O.bits_per_int8(k)
-    kchunk = (2147483647 // (S * (2 ** L - 1) ** 2)) // 64 * 64
-    assert O.gemm(op_a, op_b, m, n, k, -0.75, a.view, b.view, 1.25, c_ref.view, S, O.ORDER_DIAGONAL,
-                  kchunk=kchunk if k > kchunk else 0) == 0
-    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
-    assert np.isnan(c.buf[:, m:]).all()
-
-
-@pytest.mark.parametrize("S", [11, 12])
-def test_split_pass_zgemm_equals_single_pass_bitwise(oz, monkeypatch, S):
-    """complex products that run one launch per real product (OZIMMU_HIP_FUSED_PRODUCTS=0) may split every one of them"""
-    import torch
-    m_, h = oz
-    m, n, k = 300, 260, 512
-    g = torch.Generator(device="cuda").manual_seed(S)
-    def z(*shape):
-        return torch.complex(torch.rand(*shape, dtype=torch.float64, device="cuda", generator=g) * 2 - 1,
-                             torch.rand(*shape, dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
-    a, b, c0 = z(k, m), z(n, k), z(n, m)
-    monkeypatch.setenv("OZIMMU_HIP_FUSED_PRODUCTS", "0")
-    out = {}
-    for split in ("0", "1"):
-        monkeypatch.setenv("OZIMMU_HIP_SPLIT_PASS", split)
-        c = c0.clone()
-        assert m_.gemm(h, "N", "N", m, n, k, 0.5 - 1.5j, a, m, b, k, 0.25 + 0.75j, c, m, f"fp64_int8_{S}", m_.complx) == 0
-        _sync()
-        out[split] = torch.view_as_real(c).view(torch.int64)
-    assert torch.equal(out["0"], out["1"])
