@@ -196,6 +196,13 @@ struct K64Cfg {
   static constexpr int BREG_WA = 2;
   static constexpr bool breg_ok = S <= 9 && WA == BREG_WA && BREG_WA * S * 16 + 16 * S + 4 * 4 + 4 + 24 <= 512;
   static constexpr size_t BREG_LDS = (size_t)(2 * BREG_WA) * (2 * S) * FRAG_BYTES;
+  // VARW_ACCN | VARW_BHI (round 5): 11 staged slices.  Two A stages + one B stage of a 64 x 128 tile are 176 KiB; with the B slices
+  // 9, 10 loaded global -> named VGPRs and refilled in place (slice_gemm_y_tile.h) the B stage holds 9 slices: 88 + 72 = 160 KiB.
+  // 352 accumulator registers + 88 of B fragments: the accumulators are named registers (a[0:255], v[160:255]).
+  static constexpr int HYB_WA = 2, HYB_SLB = 9;
+  static constexpr bool hyb_ok = S == 11;
+  static constexpr size_t HYB_LDS = (size_t)(2 * HYB_WA * 2 * S + 4 * 2 * HYB_SLB) * FRAG_BYTES;
+  static_assert(!hyb_ok || (HYB_LDS <= LDS_MAX && !ok), "the hybrid form exists where the LDS form does not fit");
 };
 // (B global -> VGPR: the step has ONE form - every step prefetches, the last one wraps around - and the loop body holds two
 // steps: passes with k-blocks = 0 mod 4; kernel_policy.cpp offers the form only there.)
@@ -213,11 +220,15 @@ static hipError_t launch_wide_kernel(const SliceGemmArgs &a0, const WidePlan &pl
 template <int S, int ND>
 static hipError_t launch_wide_k64(const SliceGemmArgs &a, const WidePlan &pl, bool breg, hipStream_t stream) {
   using C = K64Cfg<ND>;
-  if constexpr (C::breg_ok) {
-    if (breg && ((a.kb1 - a.kb0) & 3u) == 0)
-      return launch_wide_kernel<S, ND, C::BREG_WA, VARW_K64 | VARW_BREG, C::DMAE, C::TAIL>(a, pl, C::BREG_LDS, stream);
+  if constexpr (C::hyb_ok) {
+    return launch_wide_kernel<S, ND, C::HYB_WA, VARW_K64 | VARW_B1 | VARW_ACCN | VARW_BHI, C::DMAE, C::TAIL>(a, pl, C::HYB_LDS, stream);
+  } else {
+    if constexpr (C::breg_ok) {
+      if (breg && ((a.kb1 - a.kb0) & 3u) == 0)
+        return launch_wide_kernel<S, ND, C::BREG_WA, VARW_K64 | VARW_BREG, C::DMAE, C::TAIL>(a, pl, C::BREG_LDS, stream);
+    }
+    return launch_wide_kernel<S, ND, C::WA, VARW_K64 | (C::NB == 1 ? VARW_B1 : 0), C::DMAE, C::TAIL>(a, pl, C::LDS, stream);
   }
-  return launch_wide_kernel<S, ND, C::WA, VARW_K64 | (C::NB == 1 ? VARW_B1 : 0), C::DMAE, C::TAIL>(a, pl, C::LDS, stream);
 }
 
 template <int S, int D0, int ND, bool X16 = false>
@@ -305,8 +316,8 @@ static constexpr PassTraits pass_traits() {
   t.wide_wa = WideCfg<S, D0, ND>::WA;
   t.x16_ok = WideCfg<S, D0, ND>::ok && PairedCfg<S, D0, ND>::ok;
   if constexpr (D0 == 0) {
-    t.k64_ok = K64Cfg<ND>::ok;
-    t.k64_wa = K64Cfg<ND>::WA;
+    t.k64_ok = K64Cfg<ND>::ok || K64Cfg<ND>::hyb_ok;
+    t.k64_wa = K64Cfg<ND>::hyb_ok ? K64Cfg<ND>::HYB_WA : K64Cfg<ND>::WA;
     t.k64_breg_ok = K64Cfg<ND>::breg_ok;
   }
   t.classic_wm4 = S <= 6 && D0 == 0 && ND == S;
@@ -343,7 +354,7 @@ static hipError_t launch_pass(const SliceGemmArgs &a, hipStream_t stream) {
     if constexpr (K2Cfg<S, D0, ND>::ok) return launch_k2<S, D0, ND>(a, stream);
     break;
   case Pick::WIDE_K64:
-    if constexpr (D0 == 0 && K64Cfg<ND>::ok) return launch_wide_k64<S, ND>(a, pl, breg, stream);
+    if constexpr (D0 == 0 && (K64Cfg<ND>::ok || K64Cfg<ND>::hyb_ok)) return launch_wide_k64<S, ND>(a, pl, breg, stream);
     break;
   case Pick::WIDE_X16:
     if constexpr (WideCfg<S, D0, ND>::ok && PairedCfg<S, D0, ND>::ok) return launch_wide<S, D0, ND, true>(a, pl, stream);

@@ -94,6 +94,97 @@ __device__ __forceinline__ void gload16_named(const int8_t *sbase, uint32_t voff
                : "memory", OZ_BREG_CLOBBERS);
 }
 
+// VARW_ACCN (slice_gemm_y_tile.h): the accumulators of the k64 tile as hand-allocated registers - tuple X < 64 in a[4X : 4X + 3],
+// tuple X >= 64 in v[160 + 4 (X - 64) : ...] (up to 24 tuples: 88 tuples = 11 diagonals on a 64 x 128 tile) - and, with VARW_BHI, the
+// B fragments of the slices j >= 9 in v[144 : 159].  The compiler never sees an accumulator: nothing for its allocator to
+// re-assign between code regions, to copy between the halves of the file or to spill (what it did to every attempt to hold 352
+// accumulator registers - or 288 next to the values of an overlapped epilogue - as C++ variables).  Every asm statement of such a
+// tile lists ALL of these registers as clobbered, so the compiler keeps no value of its own in them across any statement;
+// tests/test_isa_invariants.py checks that no compiler-generated instruction of such a kernel names an AGPR or a VGPR of the range.
+#define OZ_ACCN_V_FIRST 160
+#define OZ_BHI_FIRST 144
+#define OZ_ACCN_CLOBBERS \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
+  "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", \
+  "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", \
+  "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", \
+  "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", \
+  "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", \
+  "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+  "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", \
+  "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", \
+  "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", \
+  "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", \
+  "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", \
+  "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", \
+  "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", \
+  "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+  "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", \
+  "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", \
+  "a252", "a253", "a254", "a255", \
+  "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", \
+  "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", \
+  "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", \
+  "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", \
+  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", \
+  "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", \
+  "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", \
+  "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+template <int REG, int IMM>
+__device__ __forceinline__ void gload16_named_accn(const int8_t *sbase, uint32_t voff) {
+  static_assert(REG >= OZ_BHI_FIRST && REG + 3 < OZ_ACCN_V_FIRST && (REG & 3) == 0, "inside the B range");
+  asm volatile("global_load_dwordx4 v[%c0:%c1], %2, %3 offset:%c4"
+               :
+               : "i"(REG), "i"(REG + 3), "v"(voff), "s"(sbase), "i"(IMM)
+               : "memory", OZ_ACCN_CLOBBERS);
+}
+// accumulator tuple X += b x a.  BREG_ < 0: the B fragment is the compiler's value `b`; else v[BREG_ : BREG_ + 3]
+template <int X, int BREG_>
+__device__ __forceinline__ void mfma16_accn(const v4i &b, const v4i &a) {
+  if constexpr (X < 64) {
+    if constexpr (BREG_ < 0)
+      asm volatile("v_mfma_i32_16x16x64_i8 a[%c0:%c1], %2, %3, a[%c0:%c1]" : : "i"(4 * X), "i"(4 * X + 3), "v"(b), "v"(a) : OZ_ACCN_CLOBBERS);
+    else
+      asm volatile("v_mfma_i32_16x16x64_i8 a[%c0:%c1], v[%c2:%c3], %4, a[%c0:%c1]"
+                   :
+                   : "i"(4 * X), "i"(4 * X + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a)
+                   : OZ_ACCN_CLOBBERS);
+  } else {
+    constexpr int V = OZ_ACCN_V_FIRST + 4 * (X - 64);
+    static_assert(V + 3 <= 255, "at most 24 accumulator tuples in the VGPR half");
+    if constexpr (BREG_ < 0)
+      asm volatile("v_mfma_i32_16x16x64_i8 v[%c0:%c1], %2, %3, v[%c0:%c1]" : : "i"(V), "i"(V + 3), "v"(b), "v"(a) : OZ_ACCN_CLOBBERS);
+    else
+      asm volatile("v_mfma_i32_16x16x64_i8 v[%c0:%c1], v[%c2:%c3], %4, v[%c0:%c1]"
+                   :
+                   : "i"(V), "i"(V + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a)
+                   : OZ_ACCN_CLOBBERS);
+  }
+}
+template <int X>
+__device__ __forceinline__ void zero_accn() {
+  if constexpr (X < 64)
+    asm volatile("v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\tv_accvgpr_write_b32 a%c3, 0"
+                 :
+                 : "i"(4 * X), "i"(4 * X + 1), "i"(4 * X + 2), "i"(4 * X + 3)
+                 : OZ_ACCN_CLOBBERS);
+  else
+    asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0\n\tv_mov_b32 v%c2, 0\n\tv_mov_b32 v%c3, 0"
+                 :
+                 : "i"(OZ_ACCN_V_FIRST + 4 * (X - 64)), "i"(OZ_ACCN_V_FIRST + 4 * (X - 64) + 1), "i"(OZ_ACCN_V_FIRST + 4 * (X - 64) + 2),
+                   "i"(OZ_ACCN_V_FIRST + 4 * (X - 64) + 3)
+                 : OZ_ACCN_CLOBBERS);
+}
+// register v of tuple x -> a compiler value (the epilogue; x, v fold to constants once its loops are unrolled)
+__device__ __forceinline__ int read_accn(int x, int v) {
+  int r;
+  if (x < 64)
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "i"(4 * x + v) : OZ_ACCN_CLOBBERS);
+  else
+    asm volatile("v_mov_b32 %0, v%c1" : "=v"(r) : "i"(OZ_ACCN_V_FIRST + 4 * (x - 64) + v) : OZ_ACCN_CLOBBERS);
+  return r;
+}
+
 // MFMA slots of one k-step of a wave that owns WA blocks: block a outermost, A slice i ascending, B slice j descending
 // over the pairs with D0 <= i + j < D0 + ND, i + j <= S - 1
 template <int S, int D0, int ND, int WA>
@@ -153,6 +244,8 @@ constexpr int VARW_BAND4 = 16;     // measurement: XCD patch of 4 (M) x 8 (N) ti
 constexpr int VARW_BAND16 = 32;    // measurement: 16 x 2
 constexpr int VARW_K64 = 8192;     // k64 tile: v_mfma_i32_16x16x64_i8, one slice product over 64 k per instruction (slice_gemm_y_tile.h)
 constexpr int VARW_BREG = 16384;   // k64 tile: B fragments global -> VGPR (two register sets) instead of through a wave-private LDS stage
+constexpr int VARW_ACCN = 32768;   // k64 tile: the accumulators are NAMED registers (a[0:255] + v[160:255]), not compiler values (slice_gemm_y_tile.h)
+constexpr int VARW_BHI = 65536;    // k64 tile: the B slices j >= 9 global -> named VGPRs, refilled IN PLACE behind their last use; the rest through LDS
 constexpr int VARW_X16 = 4096;     // paired tile: v_mfma_i32_16x16x64_i8, two slice products per instruction (slice_gemm_x_tile.h)
 
 // One output tile of (32*WA) x 128: rows start at A row-block rb0, columns at B row-block 4*tn.

@@ -63,6 +63,12 @@ struct YSched {
     for (int s = s0; s < ns; s++) m = sj[s] > m ? sj[s] : m;
     return m;
   }
+  constexpr int last_use(int j, int b) const { // last slot of the step that reads B fragment (j, b)
+    int l = -1;
+    for (int s = 0; s < ns; s++)
+      if (sj[s] == j && sb[s] == b) l = s;
+    return l;
+  }
 };
 
 template <int S, int WA>
@@ -88,11 +94,24 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   constexpr bool BREG = (VARW & VARW_BREG) != 0;
   constexpr int NB = BREG ? 0 : (VARW & VARW_B1) ? 1 : 2;
   static_assert((VARW & VARW_NA3) == 0, "k64 tile: two A buffers (prefetch distance 1)");
+  // VARW_ACCN: the accumulators are named registers (slice_gemm_w_kernel.h).  VARW_BHI (with VARW_ACCN and one B buffer): the
+  // NHI highest B slices do not pass through LDS - 11 staged slices need 88 KiB for two A stages and 88 KiB for one B stage of a
+  // 64 x 128 tile, 16 KiB more than a CU has.  The fragments of the slices j >= 9 are loaded global -> v[144:159] instead and
+  // refilled IN PLACE: slice j is read by the groups i <= SL - 1 - j only, so in the step's last 16-row block its last reader is
+  // that block's group i = SL - 1 - j - for j = 10 / 9 the block's first / second group, 110 / 90 MFMA slots (~1 us) before the
+  // next step's first group asks for the new fragment.  (The low slices are needed until the step's last slots: in place they
+  // would have a few slots; they keep the LDS round trip, whose reads are issued behind the barrier.)
+  constexpr bool ACCN = (VARW & VARW_ACCN) != 0;
+  constexpr int NHI = (VARW & VARW_BHI) ? (SL > 9 ? SL - 9 : 0) : 0;
+  constexpr int SLB = SL - NHI, KSLB = 2 * SLB; // B slices staged through LDS; their blocks per row-block and step
+  static_assert(NHI == 0 || (ACCN && NB == 1 && !BREG), "in-place B slices: named accumulators, one B buffer");
+  static_assert(!ACCN || !BREG, "named accumulators: the LDS form of the tile (the register form keeps its own B sets)");
+  static_assert(NHI * 8 <= OZ_ACCN_V_FIRST - OZ_BHI_FIRST, "v[144:159] hold the in-place fragments");
   constexpr int A_STAGE = WA * KSL * FRAG_BYTES;
-  constexpr int B_STAGE = 4 * KSL * FRAG_BYTES;
+  constexpr int B_STAGE = 4 * KSLB * FRAG_BYTES;
   constexpr int OFF_B = NA * A_STAGE;
   constexpr int NQA = (WA * KSL + 3) / 4;
-  constexpr int NDMA = NQA + KSL;
+  constexpr int NDMA = NQA + (BREG ? KSL : KSLB);
   constexpr int R = RING;
   constexpr int NG = MA * SL;
   constexpr bool NO_GLOBAL = (VARW & (VARW_NO_GLOBAL | VARW_MFMA_ONLY)) != 0;
@@ -123,7 +142,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   // against src_shared_base in some instantiations, which its own verifier then rejects: "Operand has incorrect register class")
   OZ_AS3 char *const lds = (OZ_AS3 char *)smem;
   const uint32_t lds0 = (uint32_t)(size_t)lds;
-  const uint32_t ldsb0 = lds0 + OFF_B + wave * (KSL * FRAG_BYTES);
+  const uint32_t ldsb0 = lds0 + OFF_B + wave * (KSLB * FRAG_BYTES);
   auto copy_a = [&](int t, uint32_t voff, uint32_t lds_a) {
     if constexpr (NO_GLOBAL) return;
     glds16<0>(a_src[t], voff, lds_a, a_lds[t]);
@@ -131,10 +150,10 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   auto copy_b = [&](auto sc, uint32_t voff, uint32_t lds_b) {
     if constexpr (NO_GLOBAL) return;
     constexpr int c = decltype(sc)::value;          // staged block c of the wave's run
-    constexpr int kbl = c / SL, s = c % SL;         // k-block of the step, slice
+    constexpr int kbl = c / SLB, s = c % SLB;       // k-block of the step, slice
     constexpr int G = 4;                            // blocks per immediate-offset group (inside one k-block's run)
     constexpr int g0 = s / G * G;
-    glds16<(s % G) * FRAG_BYTES>(b_src + (kbl * S + g0) * FRAG_BYTES, voff, lds_b, (uint32_t)((kbl * SL + g0) * FRAG_BYTES));
+    glds16<(s % G) * FRAG_BYTES>(b_src + (kbl * S + g0) * FRAG_BYTES, voff, lds_b, (uint32_t)((kbl * SLB + g0) * FRAG_BYTES));
   };
   // VARW_BREG: B fragment (b, j) of step `kstep`, k-group g = lane >> 4, row r = lane & 15: byte
   //   ((2 kstep + (g >> 1)) * S + j) KiB + (g & 1) * 512 + (16 b + r) * 16   of the wave's row-block
@@ -148,6 +167,16 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     if constexpr (!NO_GLOBAL) {
       const uint32_t voff = vG + kstep * (uint32_t)(2 * S * FRAG_BYTES);
       gload16_named<REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
+    }
+  };
+  // VARW_BHI: fragment (b, j >= SLB) of step `kstep` -> v[OZ_BHI_FIRST + ((b * NHI) + j - SLB) * 4 ...], same addressing as load_b
+  auto load_hi = [&](auto jc, auto bc, uint32_t kstep) {
+    constexpr int j = decltype(jc)::value, b = decltype(bc)::value;
+    constexpr int G = 4, g0 = j / G * G;
+    constexpr int REG = OZ_BHI_FIRST + (b * NHI + (j - SLB)) * 4;
+    if constexpr (!NO_GLOBAL) {
+      const uint32_t voff = vG + kstep * (uint32_t)(2 * S * FRAG_BYTES);
+      gload16_named_accn<REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
     }
   };
   auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kstep, auto bnext) { // bnext: register set (VARW_BREG)
@@ -166,19 +195,26 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   };
 
   // ---- accumulators: MA x 2 x S tuples of 4 registers; the first 64 in the AGPR half ----------------------------
-  constexpr int NACC = MA * 2 * ND, NACC_A = NACC < 64 ? NACC : 64, NACC_V = NACC > 64 ? NACC - 64 : 1;
+  constexpr int NACC = MA * 2 * ND, NACC_A = ACCN ? 1 : (NACC < 64 ? NACC : 64), NACC_V = (!ACCN && NACC > 64) ? NACC - 64 : 1;
+  static_assert(!ACCN || NACC <= 88, "named accumulators: a[0:255] + v[160:255]");
   v4i accA[NACC_A], accV[NACC_V];
+  if constexpr (ACCN) {
+    static_for<NACC>([&](auto xc) { zero_accn<decltype(xc)::value>(); });
+  } else {
 #pragma unroll
-  for (int x = 0; x < NACC_A; x++)
+    for (int x = 0; x < NACC_A; x++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) accA[x][r] = 0;
+      for (int r = 0; r < 4; r++) accA[x][r] = 0;
 #pragma unroll
-  for (int x = 0; x < NACC_V; x++)
+    for (int x = 0; x < NACC_V; x++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) accV[x][r] = 0;
+      for (int r = 0; r < 4; r++) accV[x][r] = 0;
+  }
   auto mfma = [&](auto xc, const v4i &b, const v4i &a) {
     constexpr int X = decltype(xc)::value;
-    if constexpr (X < 64)
+    if constexpr (ACCN)
+      mfma16_accn<X, -1>(b, a);
+    else if constexpr (X < 64)
       mfma16_agpr(accA[X], b, a);
     else
       mfma16_vgpr(accV[X - 64], b, a);
@@ -236,13 +272,15 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   static_assert(NG >= 2, "at least two groups per step");
   static_assert(DMA0 + (NDMA - 1) * DMAE < XS, "every copy of a stage is issued before the barrier slot");
   static_assert(NB != 1 || DMA0 + NQA * DMAE >= YC.gfirst[1], "one B buffer: its refill starts behind the step's first group");
+  static_assert(NHI == 0 || (JT <= SLB && YC.last_use(SLB, 1) + 2 < XS), "in-place B slices: released, and their loads issued, before the barrier slot");
 
   const int g4 = lane >> 4;
   const uint32_t vF = (uint32_t)((g4 >> 1) * (SL * FRAG_BYTES) + (g4 & 1) * 512 + (lane & 15) * 16);
   const OZ_AS3 char *la0 = lds + vF;
-  const OZ_AS3 char *lb0 = lds + OFF_B + wave * (KSL * FRAG_BYTES) + vF;
+  const uint32_t vFB = (uint32_t)((g4 >> 1) * (SLB * FRAG_BYTES) + (g4 & 1) * 512 + (lane & 15) * 16);
+  const OZ_AS3 char *lb0 = lds + OFF_B + wave * (KSLB * FRAG_BYTES) + vFB;
   int abuf = 0, bbuf = 0;
-  v4i bj[2][SL], af[R], af0; // B fragments [column block][slice] (VARW_BREG: named registers instead)
+  v4i bj[2][SLB], af[R], af0; // B fragments [column block][slice] (VARW_BREG: named registers instead)
   auto read_a = [&](auto gc, const OZ_AS3 char *la) { // A fragment of group g -> af0 (g == 0) or ring slot (g - 1) % R
     constexpr int g = decltype(gc)::value;
     const v4i f = *(const OZ_AS3 v4i *)(la + ((YC.g_a[g] >> 1) * KSL + YC.g_i[g]) * FRAG_BYTES + (YC.g_a[g] & 1) * 256);
@@ -257,6 +295,9 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   uint32_t k_issue = koff;
   if (0u < nk) {
     static_for<NDMA>([&](auto cc) { copy_n(cc, 0, 0, k_issue, std::integral_constant<int, 0>{}); });
+    static_for<2 * NHI>([&](auto cc) {
+      load_hi(std::integral_constant<int, SLB + decltype(cc)::value / 2>{}, std::integral_constant<int, decltype(cc)::value & 1>{}, k_issue);
+    });
     k_issue = koff_next(k_issue);
   }
   prologue_hook();
@@ -268,115 +309,16 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
 #pragma unroll
       for (int b = 0; b < 2; b++)
 #pragma unroll
-        for (int j = 0; j < SL; j++) read_b(b, j, lb0);
+        for (int j = 0; j < SLB; j++) read_b(b, j, lb0);
     }
     static_for<(R < NG ? R : NG)>([&](auto gc) { read_a(gc, la0); });
   }
   asm volatile("s_nop 7" ::: "memory"); // zero-fill -> first MFMA reading it as C
 
   uint32_t it = 0;
-  auto acc = [&](int a, int b, int d, int v) -> int {
-    const int x = (a * 2 + b) * ND + d;
-    if (x >= 64) return accV[x >= 64 ? x - 64 : 0][v];
-    int r;
-    asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(accA[x < 64 ? x : 0][v]));
-    return r;
-  };
-
-  // ---- the epilogue in the shadow of the LAST step's MFMAs (VARW_BREG kernels) ---------------------------------------------------
-  // The tile boundary of this kernel IS the FP64 recombination (profiles/r4_ablate/r4l_tile_boundary_...: 3.8 - 4.0 us per 64 x 128
-  // tile whatever K is - 9 x (v_accvgpr_read + v_cvt_f64_i32 + v_fma_f64) per output, ~4 000 VALU cycles per wave with the matrix
-  // pipe idle; 11 % of the kernel at K = 512, 7 % at K = 1024).  A step walks the 16-row blocks a = 0 .. MA-1 one after the other,
-  // so in the last step the accumulators of block a are final once its MFMAs have issued: their recombination is cut into
-  // micro-operations (one diagonal of one column pair: 2 reads, 2 conversions, 2 fma) that are issued BETWEEN the MFMAs of block
-  // a + 1 - a wave issues VALU work while the matrix pipe works off a 16-cycle MFMA -, and only the last block's recombination is
-  // left behind the k loop.  Same operations on every element in the same order as recombine_and_store16 (its 16-byte store form):
-  // bit-identical.  Interior tiles of a real, final, single-chunk product with an even ldc and a 16-byte aligned C (what that
-  // store form asks for); every other tile takes the plain last step and the plain epilogue.  The condition is uniform over the
-  // WORKGROUP (the overlapped last step has no barrier: its waves must agree on the number of barriers they pass).
-  constexpr int EPU = ND + 3;                 // micro-operations per unit (column pair of a 16 x 16 block): begin, ND diagonals, scale, store
-  constexpr int EPB = 4 * EPU;                // ... per 16-row block: units (b, vp) = 2 column blocks x 2 column pairs
-  constexpr int SPA = NS / MA;                // MFMA slots per 16-row block
-  constexpr int EPI_T0 = 3;                   // first micro-operation this many slots into the next block (the last MFMA of the finished
-                                              // block is two slots = 32 cycles old: XDL write -> VALU read needs 11 wait states)
-  constexpr bool OVERLAP_BUILT = BREG && !NO_GLOBAL && !MFMA_ONLY && ((VARW >> 8) & 3) == 0 && (VARW & VARW_NO_EPILOGUE) == 0 &&
-                                 SPA * MA == NS && SPA >= EPB + EPI_T0 + 2;
-  const uint32_t e_mu = rb0 * 32u, e_nu = tn * 128u + (uint32_t)wave * 32u;
-  bool overlap = false;
-  if constexpr (OVERLAP_BUILT) {
-    overlap = p.epi_overlap && p.final && !p.cplx && !p.acc_in && e_mu + 16u * MA <= p.M && tn * 128u + 128u <= p.N &&
-              (p.ldc & 1u) == 0 && p.ldc < (1u << 26) && (reinterpret_cast<uintptr_t>(p.c) & 15u) == 0 && nk >= 2;
-#ifdef OZIMMU_HIP_TEST_HOOKS
-    overlap = overlap && !p.dump;
-#endif
-  }
-  double e_sc[OVERLAP_BUILT ? ND : 1], e_ea[OVERLAP_BUILT ? MA : 1], e_eb[OVERLAP_BUILT ? 8 : 1];
-  double e_x0 = 0, e_x1 = 0, e_v0 = 0, e_v1 = 0;
-  double2 e_old[OVERLAP_BUILT ? 4 : 1];
-  uint32_t e_boff = 0;
-  bool e_odd = false, e_rmw = false;
-  auto e_colp = [&](uint32_t cofs, int A) { // wave-uniform: column nu + cofs (+ nl per lane, in e_boff), first row of block A
-    return reinterpret_cast<char *>(p.c + ((size_t)(e_nu + cofs) * p.ldc + e_mu)) + 128 * A;
-  };
-  auto epi_setup = [&]() { // issued a block's worth of MFMAs ahead of the first use: exponents, the old C of block 0
-    const uint32_t nl = 4u * ((uint32_t)lane >> 4);
-    e_odd = (lane & 1) != 0;
-    e_rmw = p.beta != 0.0;
-    e_boff = ((nl + ((uint32_t)lane & 1u)) * (uint32_t)p.ldc + ((uint32_t)lane & 14u)) * 8u;
-#pragma unroll
-    for (int d = 0; d < ND; d++) e_sc[d] = pow2d(46 - p.L * (D0 + d + 2));
-#pragma unroll
-    for (int a = 0; a < MA; a++) e_ea[a] = p.ea[e_mu + ((uint32_t)lane & 15u) + 16 * a];
-    const double *eb_lane = p.eb + e_nu + nl;
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int v = 0; v < 4; v++) e_eb[4 * b + v] = eb_lane[16 * b + v];
-    if (e_rmw) {
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        e_old[u] = *reinterpret_cast<const double2 *>(e_colp(16 * (u >> 1) + 2 * (u & 1), 0) + (size_t)e_boff);
-    }
-  };
-  // micro-operation m of block A (compile-time indices)
-  auto epi_micro = [&](auto a_tag, auto m_tag) {
-    constexpr int A = decltype(a_tag)::value, m = decltype(m_tag)::value;
-    constexpr int u = m / EPU, q = m % EPU, b = u >> 1, vp = u & 1;
-    constexpr uint32_t cofs = 16 * b + 2 * vp;
-    if constexpr (q == 0) {
-      e_x0 = e_x1 = 0.0;
-    } else if constexpr (q <= ND) {
-      constexpr int d = q - 1;
-      e_x0 = fma((double)acc(A, b, d, 2 * vp), e_sc[d], e_x0);
-      e_x1 = fma((double)acc(A, b, d, 2 * vp + 1), e_sc[d], e_x1);
-    } else if constexpr (q == ND + 1) {
-      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
-      e_v0 = e_x0 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp];
-      e_v1 = e_x1 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp + 1];
-    } else {
-      const double s0 = lane_pair_swap(e_v0), s1 = lane_pair_swap(e_v1);
-      double2 y;
-      y.x = e_odd ? s1 : e_v0; // row 2i:     (column n from this lane | column n+1 from the even neighbour)
-      y.y = e_odd ? e_v1 : s0; // row 2i + 1: (column n from the odd neighbour | column n+1 from this lane)
-      char *cp = e_colp(cofs, A) + (size_t)e_boff;
-      if (e_rmw) {
-        y.x = fma(p.alpha, y.x, p.beta * e_old[u].x);
-        y.y = fma(p.alpha, y.y, p.beta * e_old[u].y);
-        if constexpr (A + 1 < MA) // the old values of the next block's unit u: a block's worth of MFMAs ahead of their use
-          e_old[u] = *reinterpret_cast<const double2 *>(e_colp(cofs, A + 1) + (size_t)e_boff);
-      } else {
-        y.x = p.alpha * y.x;
-        y.y = p.alpha * y.y;
-      }
-      *reinterpret_cast<double2 *>(cp) = y;
-    }
-  };
-
   // PAR (VARW_BREG): the register set this step multiplies out of; the next step's fragments are loaded into the other one
-  // EPI: the overlapped last step (above)
-  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag, auto epi_tag) {
-    constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value, EPI = decltype(epi_tag)::value;
-    static_assert(!EPI || (!PF && !NX), "the overlapped last step prefetches nothing and meets no barrier");
+  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag) {
+    constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value;
     constexpr int PC = BREG ? decltype(par_tag)::value : 0, PN = BREG ? (PC ^ 1) : 0;
     const int abuf_n = abuf ^ 1;
     const int abuf_pf = abuf_n, bbuf_pf = NB == 1 ? 0 : (bbuf ^ 1);
@@ -422,30 +364,27 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
       else if constexpr (BREG)
         mfma_named(std::integral_constant<int, X>{}, std::integral_constant<int, OZ_BREG_FIRST + ((PC * 2 + b) * SL + j) * 4>{},
                    g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
+      else if constexpr (j >= SLB) // VARW_BHI: the fragment in its named registers
+        mfma16_accn<X, OZ_BHI_FIRST + (b * NHI + (j - SLB)) * 4>(af0, g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       else
-        mfma(std::integral_constant<int, X>{}, bj[b][j], g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
-      if constexpr (EPI) {
-        if constexpr (s == 1) {
-          epi_setup();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (a >= 1) { // block a - 1 is final: its micro-operations EPI_T0 .. spread over this block's slots
-          constexpr int t = s - a * SPA;
-          static_for<EPB>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            if constexpr (EPI_T0 + m * (SPA - EPI_T0 - 1) / EPB == t) epi_micro(std::integral_constant<int, a - 1>{}, mc);
-          });
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        mfma(std::integral_constant<int, X>{}, bj[b][j < SLB ? j : 0], g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
+      if constexpr (PF && NHI > 0) { // the next step's fragment into the registers whose last reader has issued two slots ago
+        static_for<2 * NHI>([&](auto cc) {
+          constexpr int jh = SLB + decltype(cc)::value / 2, bh = decltype(cc)::value & 1;
+          if constexpr (YC.last_use(jh, bh) + 2 == s) {
+            load_hi(std::integral_constant<int, jh>{}, std::integral_constant<int, bh>{}, kb_pf);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
       }
       if constexpr (s >= XS && NX && !MFMA_ONLY) {
         if constexpr (!BREG) {
-          constexpr int NREF = 2 * (SL - JT);                 // fragments refreshed behind the barrier
+          constexpr int NREF = 2 * (SLB - JT);                // fragments refreshed behind the barrier
           constexpr int RPT = (NREF + TAIL - 1) / TAIL;
 #pragma unroll
           for (int u = 0; u < RPT; u++) {
-            const int idx = (s - XS) * RPT + u;               // (j descending from S-1, b)
-            if (idx < NREF) read_b(idx & 1, SL - 1 - (idx >> 1), lb_n);
+            const int idx = (s - XS) * RPT + u;               // (j descending from SLB-1, b)
+            if (idx < NREF) read_b(idx & 1, SLB - 1 - (idx >> 1), lb_n);
           }
         }
         if constexpr (s == XS + 1 || (TAIL == 1 && s == XS))
@@ -481,41 +420,31 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     // an even number of steps only (slice_gemm_launch.h).
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    using NO = std::false_type;
-    if constexpr (OVERLAP_BUILT) {
-      if (overlap) {
-        for (; it + 2 < nk;) {
-          step(std::true_type{}, std::true_type{}, P0{}, NO{});
-          it++;
-          step(std::true_type{}, std::true_type{}, P1{}, NO{});
-          it++;
-        }
-        step(std::true_type{}, std::true_type{}, P0{}, NO{});
-        it++;
-        step(NO{}, NO{}, P1{}, std::true_type{}); // nothing prefetched, no barrier; blocks 0 .. MA-2 recombined and stored
-        it++;
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulators
-        static_for<EPB>([&](auto mc) { epi_micro(std::integral_constant<int, MA - 1>{}, mc); });
-        return;
-      }
-    }
     for (; it < nk;) {
-      step(std::true_type{}, std::true_type{}, P0{}, NO{});
+      step(std::true_type{}, std::true_type{}, P0{});
       it++;
-      step(std::true_type{}, std::true_type{}, P1{}, NO{});
+      step(std::true_type{}, std::true_type{}, P1{});
       it++;
     }
   } else {
     using P0 = std::integral_constant<int, 0>;
-    using NO = std::false_type;
-    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{}, NO{});
+    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{});
     if constexpr (PD > 1)
-      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{}, NO{});
-    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{}, NO{});
+      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{});
+    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{});
   }
 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulator
+  auto acc = [&](int a, int b, int d, int v) -> int {
+    const int x = (a * 2 + b) * ND + d;
+    if constexpr (ACCN) return read_accn(x, v);
+    if (x >= 64) return accV[x >= 64 ? x - 64 : 0][v];
+    int r;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(accA[x < 64 ? x : 0][v]));
+    return r;
+  };
   if constexpr ((VARW & VARW_NO_EPILOGUE) != 0) {
+    static_assert(!ACCN, "named accumulators need no keep-alive");
 #pragma unroll
     for (int x = 0; x < NACC_A; x++) asm volatile("" ::"a"(accA[x]));
 #pragma unroll

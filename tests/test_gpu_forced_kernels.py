@@ -30,7 +30,8 @@ FORCED_ARMS = {
     "k64_breg": {"OZIMMU_HIP_GEMM_KERNEL": "k64", "OZIMMU_HIP_K64_BREG": "1"},
 }
 # a single-pass mode every arm is built for (k64_breg: 9 staged diagonals; x16 at S = 9 is not instantiated: S = 12)
-ARM_MODES = {"k2": [4, 9], "classic": [3, 9, 12], "wide": [4, 9, 11], "x16": [12, 10], "k64": [4, 9, 10], "k64_breg": [9]}
+# (k64 at S = 11: the round-5 form with named accumulator registers and the B slices 9, 10 refilled in place)
+ARM_MODES = {"k2": [4, 9], "classic": [3, 9, 12], "wide": [4, 9, 11], "x16": [12, 10, 11], "k64": [4, 9, 10, 11], "k64_breg": [9]}
 
 
 def _sync():
@@ -151,7 +152,7 @@ def test_persistent_launch_forms_bit_exact_vs_oracle(oz, monkeypatch, m, n, k, b
 
 
 @pytest.mark.parametrize("grid", [1, 3, 7])
-@pytest.mark.parametrize("arm,S", [("wide", 9), ("wide", 6), ("x16", 12), ("k64", 9), ("k64_breg", 9), ("k64", 6)])
+@pytest.mark.parametrize("arm,S", [("wide", 9), ("wide", 6), ("x16", 12), ("k64", 9), ("k64_breg", 9), ("k64", 6), ("k64", 11)])
 @pytest.mark.parametrize("m,n,k", [(700, 520, 128), (333, 900, 256)])
 def test_few_persistent_workgroups_walk_many_tiles(oz, monkeypatch, arm, S, m, n, k, grid):
     """OZIMMU_HIP_WIDE_GRID = g on a small problem: the call gets phase lines and claim counters (api.cpp: wants_phase) and g
@@ -170,3 +171,33 @@ def test_few_persistent_workgroups_walk_many_tiles(oz, monkeypatch, arm, S, m, n
     assert m_.last_kernel(h)[0] == arm
     assert O.gemm("T", "N", m, n, k, 1.5, a.view, b.view, -0.5, c_ref.view, S, O.ORDER_DIAGONAL) == 0
     np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+
+
+# ---- the register kernel's store forms inside one launch -----------------------------------------------------------------------
+# Interior tiles of a real, final product with an even ldc and a 16-byte aligned C store 16 bytes per lane through the lane-pair
+# exchange; edge tiles, odd ldc and misaligned C take the 8-byte form - every case below mixes both inside one launch, with
+# several tiles per workgroup where a grid is given.  (Written for the round-5 attempt to recombine under the last k-step's MFMAs,
+# profiles/r5_ablate/r5c_*: the attempt is out, the cases stay.)
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (-0.75, 1.25)])
+@pytest.mark.parametrize("m,n,k,ld_pad,grid", [(389, 257, 256, 3, 0), (389, 257, 256, 2, 0), (200, 300, 128, 0, 0), (640, 512, 512, 0, 0),
+                                               (700, 520, 1024, 4, 3), (96, 256, 2048, 0, 0), (2048, 1536, 256, 0, 0)])
+def test_register_kernel_store_forms_bit_exact_vs_oracle(oz, monkeypatch, m, n, k, ld_pad, grid, alpha, beta):
+    m_, h = oz
+    S = 9
+    extra = {}
+    if grid:
+        extra["OZIMMU_HIP_WIDE_GRID"] = grid
+    _force(monkeypatch, "k64_breg", **extra)
+    rng = np.random.default_rng(m + 3 * n + 5 * k + ld_pad)
+    a = operand("N", m, k, rng)
+    b = operand("T", k, n, rng, pad=1)
+    c = ColMajor(m, n, ld=m + ld_pad, fill=uniform_pm1, rng=rng)
+    c_ref = ColMajor(m, n, ld=m + ld_pad)
+    c_ref.buf[...] = c.buf
+    assert m_.gemm(h, "N", "T", m, n, k, alpha, a.dev, a.ld, b.dev, b.ld, beta, c.dev, c.ld, f"fp64_int8_{S}") == 0
+    _sync()
+    assert m_.last_kernel(h)[0] == "k64_breg"
+    assert O.gemm("N", "T", m, n, k, alpha, a.view, b.view, beta, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+    np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+    if ld_pad:
+        assert np.isnan(c.buf[:, m:]).all()  # ld padding untouched

@@ -190,7 +190,8 @@ def test_named_b_registers_are_untouched_by_the_compiler(asm):
     compiler may use the range before the first load of a tile function and after its last MFMA (the epilogue), never in
     between - a compiler-generated instruction there (a spill reload, an address temporary) would corrupt a fragment."""
     ks = {**_kernels(asm["slice_gemm.hip"], "slice_gemm_w_kernel"), **_kernels(asm["slice_gemm.hip"], "slice_gemm_w_multi_kernel")}
-    breg = {n: b for n, b in ks.items() if "global_load_dwordx4 v[" in b}
+    # (the named-accumulator kernels load their in-place B slices into v[144:159]: their own test below)
+    breg = {n: b for n, b in ks.items() if re.search(r"global_load_dwordx4 v\[11[2-9]:", b)}
     assert len(breg) >= 2, "no VARW_BREG kernel in the library"
     for name, body in breg.items():
         lines = body.split("\n")
@@ -265,3 +266,38 @@ def test_returning_atomics_are_waited_for_before_their_destination_is_touched(as
         else:
             pytest.fail(f"line {i}: no vmcnt(0) wait after {l.strip()}")
     assert seen >= 20 and hand >= 4, (seen, hand)   # every persistent kernel claims; the k64 kernels also speculate
+
+
+def test_named_accumulator_kernels_keep_the_compiler_out_of_their_registers(asm):
+    """VARW_ACCN kernels (slice_gemm_w_kernel.h: fp64_int8_11 on the k64 tile) hold their 352 accumulator registers in a[0:255] and
+    v[160:255] and two in-place B slices in v[144:159] as NAMED registers: written and read by inline asm only, every statement
+    listing the whole set as clobbered.  The compiler must neither use them for its own values (a temporary between two statements
+    would destroy a sum) nor spill: no compiler-generated instruction names an AGPR or a VGPR >= 144, no scratch, and the kernel
+    descriptor gives the wave the whole file (256 + 256)."""
+    ks = _kernels(asm["slice_gemm.hip"], "slice_gemm_w_kernel")
+    def varw(name):     # slice_gemm_w_kernel<S, D0, ND, WA, VARW, ...>: the fifth template argument
+        m = re.search(r"kernelILi\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)
+        return int(m.group(1)) if m else 0
+    accn = {n: b for n, b in ks.items() if varw(n) & 32768}   # VARW_ACCN
+    assert len(accn) >= 1, "no named-accumulator kernel in the library"
+    for name, body in accn.items():
+        assert "scratch_" not in body, name
+        in_asm = False
+        mfmas = 0
+        for l in body.split("\n"):
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif in_asm:
+                mfmas += "v_mfma" in l
+            elif not l.strip().startswith(";"):
+                assert "v_mfma" not in l, f"{name}: an MFMA outside inline asm"
+                regs = {int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", l)}
+                for m in re.finditer(r"\bv\[(\d+):(\d+)\]", l):
+                    regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                assert not any(r >= 144 for r in regs), f"{name}: compiler code in the named VGPR range: {l.strip()}"
+                assert not re.search(r"\ba\d+\b|\ba\[\d+:\d+\]", l), f"{name}: compiler code names an AGPR: {l.strip()}"
+        assert mfmas >= 1000, (name, mfmas)
+        meta = re.search(re.escape(name) + r"\.kd.*?\.vgpr_count:\s+(\d+)", asm["slice_gemm.hip"], flags=re.S)
+        assert meta and int(meta.group(1)) == 512, name

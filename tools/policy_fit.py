@@ -33,10 +33,19 @@ SWITCHES = ("OZIMMU_HIP_GEMM_KERNEL", "OZIMMU_HIP_K64_BREG")
 KERNELS = ["k2", "classic", "wide", "x16", "k64", "k64_breg"]
 
 
-def shapes(count, seed, modes):
+def shapes(count, seed, modes, kind="mixed"):
     import numpy as np
     rng = np.random.default_rng(seed)
     out = []
+    if kind == "shortk":  # large outputs over short k loops (panel updates): where the round-4 fit had few cases and missed
+        for _ in range(count):
+            m, n = (int(rng.choice([4096, 6144, 8192, 12288, 16384, 24576, 32768])) if rng.random() < 0.5 else int(rng.integers(4000, 20000))
+                    for _ in range(2))
+            k = int(rng.choice([128, 256, 384, 512, 768]))
+            if m * n > 6e8:
+                m, n = min(m, 24576), min(n, 24576)
+            out.append((m, n, k, int(rng.choice(modes))))
+        return out
     fixed = [(1024, 1024, 1024), (1536, 1536, 1536), (2048, 2048, 2048), (3072, 3072, 3072), (4096, 4096, 4096),
              (8192, 8192, 8192), (8192, 8192, 1024), (4096, 4096, 512), (16384, 16384, 256), (768, 768, 768)]
     for m, n, k in fixed:
@@ -64,7 +73,7 @@ def collect(args):
     oz.set_cuda_stream(h, torch.cuda.current_stream())
     info = oz.device_info(h)
     f = open(args.out, "a")
-    for (m, n, k, S) in shapes(args.count, args.seed, args.modes):
+    for (m, n, k, S) in shapes(args.count, args.seed, args.modes, args.kind):
         a = torch.rand(k, m, dtype=torch.float64, device="cuda") * 2 - 1
         b = torch.rand(n, k, dtype=torch.float64, device="cuda") * 2 - 1
         c = torch.zeros(n, m, dtype=torch.float64, device="cuda")
@@ -261,6 +270,7 @@ if __name__ == "__main__":
     c.add_argument("--count", type=int, default=120)
     c.add_argument("--seed", type=int, default=0)
     c.add_argument("--modes", type=int, nargs="*", default=[4, 6, 8, 9, 10, 12])
+    c.add_argument("--kind", default="mixed", choices=["mixed", "shortk"])
     f_ = sub.add_parser("fit")
     f_.add_argument("data", nargs="+")
     f_.add_argument("--out", default=None)
