@@ -63,6 +63,16 @@ def test_c2_fp64_int8_9_8192(oz):
     C3 = torch.empty_like(C)
     _gemm(m_, h, "N", "N", n, n, n, A3, B, C3, "fp64_int8_9")
     assert torch.equal(C3, C[:, perm])
+    # and bits, not only properties: two 256 x 256 blocks of the 8192^3 result (an interior one that straddles tile and XCD-patch
+    # boundaries, and the last corner) against the oracle on the same 256 rows of A and 256 columns of B over the full K.
+    # Rows and columns are cut independently of each other, so the block of the full product IS the product of the sub-matrices.
+    for r0, c0 in ((4000, 1936), (n - 256, n - 256)):
+        a_sub = A[:, r0:r0 + 256].contiguous().cpu().numpy().T        # 256 x K, column-major
+        b_sub = B[c0:c0 + 256, :].contiguous().cpu().numpy().T        # K x 256, column-major
+        c_ref = np.zeros((256, 256), order="F")
+        assert O.gemm("N", "N", 256, 256, n, 1.0, a_sub, b_sub, 0.0, c_ref, 9, O.ORDER_DIAGONAL) == 0
+        got = C[c0:c0 + 256, r0:r0 + 256].cpu().numpy().T
+        np.testing.assert_array_equal(got.view(np.uint64), np.ascontiguousarray(c_ref).view(np.uint64))
 
 
 def test_c3_slice_sweep_4096_wide_exponent(oz):
