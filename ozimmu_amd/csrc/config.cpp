@@ -50,6 +50,7 @@ static Config read_config() {
   c.no_phase_hint = flag("OZIMMU_HIP_NO_PHASE_HINT", false);
   c.phase_min_kb = (int)number("OZIMMU_HIP_PHASE_MIN_KB", c.phase_min_kb);
   c.spec_claim_kb = (int)number("OZIMMU_HIP_SPEC_CLAIM_KB", c.spec_claim_kb);
+  c.epi_overlap = flag("OZIMMU_HIP_EPI_OVERLAP", true);
   c.static_rounds = (int)number("OZIMMU_HIP_STATIC_ROUNDS", c.static_rounds);
   c.batch_loop = flag("OZIMMU_HIP_BATCH_LOOP", false);
   c.split_band_bytes = (size_t)number("OZIMMU_HIP_SPLIT_BAND_BYTES", 0);

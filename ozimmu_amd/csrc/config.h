@@ -25,6 +25,7 @@ struct Config {
   bool no_exp_reuse = false;   // OZIMMU_HIP_NO_EXP_REUSE: auto mode recomputes the row maxima in the GEMM
   int phase_min_kb = 32;       // OZIMMU_HIP_PHASE_MIN_KB: passes of at most this many k-blocks run without the phase hint
   int static_rounds = 20;      // OZIMMU_HIP_STATIC_ROUNDS: up to this many EXACT rounds of tiles run as a static grid instead of persistent workgroups (0: never)
+  bool epi_overlap = true;     // OZIMMU_HIP_EPI_OVERLAP=0: the k64 register kernels keep the whole FP64 recombination behind their k loop
   int spec_claim_kb = 64;      // OZIMMU_HIP_SPEC_CLAIM_KB: k loops of at most this many k-blocks claim the next tile one tile ahead (0: never)
   bool no_phase_hint = false;  // OZIMMU_HIP_NO_PHASE_HINT
   bool batch_loop = false;     // OZIMMU_HIP_BATCH_LOOP: strided batches as a per-matrix loop

@@ -36,7 +36,10 @@ enum : int {
   CL_DRIFT,    // the 64 x 64 tiles lose L2 panel sharing over a long k loop (their workgroups drift apart): the classic kernel's
                // MFMA work x (1 + CL_DRIFT x (log2(k-blocks) - 5) / 3) beyond 32 k-blocks (= 1 + CL_DRIFT at K = 8192)
   ST_H,        // wide family: the exposed part of a tile's C stores, per 32-row block (one workgroup per CU: nothing overlaps them)
-  SPARE2, SPARE3, SPARE4,
+  CL_EPI,      // the 64 x 64 kernels' recombination per tile and diagonal (a short k loop under a large output: a fifth of the tile)
+  CL_C_US_PER_MB, // ... and what the 64 x 64 kernels' store of C costs per MB (8-byte stores from 2 x 256 workgroups; the wide family: C_US_PER_MB + ST_H)
+  CL_ROUND,    // 64 x 64 tiles, form 0: what every round of tiles beyond the first costs on top (tile switch with both workgroups of a CU
+               // in their prologue / epilogue at once: the steady state of many rounds, which a single round does not show)
   DEV_CUS, DEV_MFMA_US // not model constants: the device of a prediction made without a handle (api.cpp)
 };
 static_assert(DEV_MFMA_US + 1 == POLICY_PARAMS, "parameter table");
@@ -55,7 +58,9 @@ static double g_params[POLICY_PARAMS] = {
     /* wide f, gamma, epi_w, epi_y    */ 1.681, 0.7697, 0.08047, 0.09886,
     /* C us per MB                    */ 0.1775,
     /* cl drift, store per block      */ 0, 0.7782,
-    0, 0, 0, 0.0, 0.0};
+    /* cl epi, cl C us per MB */ 0, 0.1775,
+    /* cl round */ 0,
+    0.0, 0.0};
 
 static std::mutex g_params_mtx;
 void policy_params_get(double out[POLICY_PARAMS]) {
@@ -86,7 +91,8 @@ Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topo
   const uint64_t tiles64 = (uint64_t)((in.M + 63) / 64) * ((in.N + 63) / 64) * batch;
   const Config::Kernel forced = cfg.gemm_kernel;
   const bool is_forced = cfg.forced_kernel();
-  const double c_us = p[C_US_PER_MB] * 8e-6 * (double)in.M * (double)in.N * (double)batch; // the store of C, whatever the kernel
+  const double c_us = p[C_US_PER_MB] * 8e-6 * (double)in.M * (double)in.N * (double)batch; // the store of C (wide family)
+  const double c_us_cl = p[CL_C_US_PER_MB] * 8e-6 * (double)in.M * (double)in.N * (double)batch; // ... of the 64 x 64 kernels
   auto boost = [&](double busy_fraction) { // < 1: few busy CUs clock higher under the package power cap
     const double phi = busy_fraction < 1.0 ? busy_fraction : 1.0;
     return p[GAMMA] + (1.0 - p[GAMMA]) * phi;
@@ -97,7 +103,7 @@ Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topo
   if (t.k2_ok && (forced == Config::K2 || (!is_forced && tiles64 <= (uint64_t)cus && in.nkb >= 4))) {
     const uint64_t rounds = (tiles64 + (uint64_t)cus - 1) / (uint64_t)cus; // > 1 only when forced
     // (each of the two wave groups walks half of the k-blocks)
-    r.us[(int)Pick::K2] = c_us + p[K2_F] + (double)rounds * (w * g64 * (p[K2_A] + p[K2_BETA] * rho64) + 0.5 * in.nkb * p[K2_STEP]);
+    r.us[(int)Pick::K2] = c_us_cl + p[K2_F] + (double)rounds * (w * g64 * (p[K2_A] + p[K2_BETA] * rho64) + 0.5 * in.nkb * p[K2_STEP] + p[CL_EPI] * t.ND);
   }
 
   // ---- classic kernel: 64 x 64 tiles of 4 waves, two workgroups per CU (S <= 6 on many tiles: 128 x 64 tiles of 8 waves) --
@@ -109,21 +115,21 @@ Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topo
     double T;
     if (t.classic_form == 0) {
       const uint64_t slots = 2ull * (uint64_t)cus, q = tiles64 / slots, rem = tiles64 % slots;
-      const double st = (double)in.nkb * p[CL_STEP];
-      T = p[CL_F] + (double)q * (2.0 * w * e2 + st + p[CL_B]);
+      const double st = (double)in.nkb * p[CL_STEP] + p[CL_EPI] * t.ND;
+      T = p[CL_F] + (double)q * (2.0 * w * e2 + st + p[CL_B]) + (q > 1 ? (double)(q - 1) * p[CL_ROUND] : 0.0);
       if (rem) T += rem <= (uint64_t)cus ? (w * e1 + st + p[CL_B]) : (2.0 * w * e2 + st + p[CL_B]);
     } else if (t.classic_form == 1) { // 11-13 staged slices: one 8-wave 128 x 64 workgroup per CU (two blocks per SIMD)
       const uint64_t rounds = (tiles128 + (uint64_t)cus - 1) / (uint64_t)cus;
-      T = p[CL_F] + (double)rounds * (2.0 * w * drift * (p[CL4_A] + p[CL_BETA] * 0.75 * rho64) + in.nkb * p[CL4_STEP] + p[CL_B]);
+      T = p[CL_F] + (double)rounds * (2.0 * w * drift * (p[CL4_A] + p[CL_BETA] * 0.75 * rho64) + in.nkb * p[CL4_STEP] + p[CL_B] + 2.0 * p[CL_EPI] * t.ND);
     } else { // 14+ staged slices: 64 x 64, one workgroup per CU
       const uint64_t rounds = (tiles64 + (uint64_t)cus - 1) / (uint64_t)cus;
-      T = p[CL_F] + (double)rounds * (w * e1 + in.nkb * p[CL_STEP] + p[CL_B]);
+      T = p[CL_F] + (double)rounds * (w * e1 + in.nkb * p[CL_STEP] + p[CL_B] + p[CL_EPI] * t.ND);
     }
-    r.us[(int)Pick::CLASSIC] = c_us + T;
-    T += c_us;
+    r.us[(int)Pick::CLASSIC] = c_us_cl + T;
+    T += c_us_cl;
     if (t.classic_wm4 && tiles128 >= 512) { // (the threshold of launch_S: the 8-wave form needs enough tiles to fill the chip)
       const uint64_t rounds = (tiles128 + (uint64_t)cus - 1) / (uint64_t)cus;
-      const double T4 = c_us + p[CL_F] + (double)rounds * (2.0 * w * drift * (p[CL4_A] + p[CL_BETA] * 0.75 * rho64) + in.nkb * p[CL4_STEP] + p[CL_B]);
+      const double T4 = c_us_cl + p[CL_F] + (double)rounds * (2.0 * w * drift * (p[CL4_A] + p[CL_BETA] * 0.75 * rho64) + in.nkb * p[CL4_STEP] + p[CL_B] + 2.0 * p[CL_EPI] * t.ND);
       if (T4 < T) {
         r.us[(int)Pick::CLASSIC] = T4;
         r.classic_wm4 = true;

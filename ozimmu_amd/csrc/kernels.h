@@ -43,6 +43,7 @@ struct SliceGemmArgs {
   uint32_t phase_min_kb; // passes of at most this many k-blocks run without the phase hint (filled in by launch_slice_gemm)
   uint32_t spec_claim_kb; // persistent k64 kernels: passes of at most this many k-blocks draw the next tile's ticket one tile ahead
                           // (slice_gemm_w_kernel.h; filled in by launch_slice_gemm; 0: never)
+  uint32_t epi_overlap; // k64 register kernels: recombine the finished row blocks in the shadow of the last step's MFMAs (filled in by launch_slice_gemm)
   uint32_t throttle; // 0: off; else a workgroup that runs ahead of `phase` sleeps (probed every 16th k-step)
   // test hook, compiled only with -DOZIMMU_HIP_TEST_HOOKS (libozimmu_hip_test.so, loaded by the tests that need a hook; the
   // library that ships, libozimmu_hip.so, carries none: ozimmu_amd/build.py): INT32 diagonal sums

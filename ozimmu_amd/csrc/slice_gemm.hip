@@ -93,6 +93,7 @@ hipError_t launch_slice_gemm_fused(int S, const SliceGemmArgs *g_in, int count, 
     g[i].nxcd = nx;
     g[i].phase_min_kb = (uint32_t)config().phase_min_kb;
     g[i].spec_claim_kb = (uint32_t)config().spec_claim_kb;
+    g[i].epi_overlap = config().epi_overlap ? 1u : 0u;
   }
 #define OZ_FUSED_PART(LO, HI, NAME) \
   if (S >= LO && S <= HI) return launch_slice_gemm_fused_##NAME(S, g, count, stream);
@@ -106,6 +107,7 @@ hipError_t launch_slice_gemm(int S, const SliceGemmArgs &a_in, hipStream_t strea
   a.nxcd = (uint32_t)topology(a.device).xcds; // the kernels' tile partition and per-XCD lines follow the device (topology.h)
   a.phase_min_kb = (uint32_t)config().phase_min_kb;
   a.spec_claim_kb = (uint32_t)config().spec_claim_kb;
+  a.epi_overlap = config().epi_overlap ? 1u : 0u;
 #define OZ_LAUNCH_PART(LO, HI, NAME) \
   if (S >= LO && S <= HI) return launch_slice_gemm_##NAME(S, a, stream);
   OZ_GEMM_PARTS(OZ_LAUNCH_PART)

@@ -191,16 +191,17 @@ struct K64Cfg {
   static constexpr size_t LDS = lds(WA > 0 ? WA : 1, NB);
   static constexpr int DMAE = 8, TAIL = 12;
   // VARW_BREG (slice_gemm_y_tile.h): the B fragments global -> VGPR into two named register sets of 2 * S fragments
-  // (v[112:255]: S <= 9), LDS holds the two A stages only.  64 x 128 tiles; where the LDS form has the same tile height it
+  // (v[80:223]: S <= 9; the accumulators are named registers too: a[0:255], v[224:255]), LDS holds the two A stages only.  64 x 128 tiles; where the LDS form has the same tile height it
   // stages a third of the bytes into LDS and reads two thirds of the fragments from it.
   static constexpr int BREG_WA = 2;
   static constexpr bool breg_ok = S <= 9 && WA == BREG_WA && BREG_WA * S * 16 + 16 * S + 4 * 4 + 4 + 24 <= 512;
   static constexpr size_t BREG_LDS = (size_t)(2 * BREG_WA) * (2 * S) * FRAG_BYTES;
-  // VARW_ACCN | VARW_BHI (round 5): 11 staged slices.  Two A stages + one B stage of a 64 x 128 tile are 176 KiB; with the B slices
-  // 9, 10 loaded global -> named VGPRs and refilled in place (slice_gemm_y_tile.h) the B stage holds 9 slices: 88 + 72 = 160 KiB.
-  // 352 accumulator registers + 88 of B fragments: the accumulators are named registers (a[0:255], v[160:255]).
-  static constexpr int HYB_WA = 2, HYB_SLB = 9;
-  static constexpr bool hyb_ok = S == 11;
+  // VARW_ACCN | VARW_BHI (round 5): 11 and 12 staged slices.  Two A stages + one B stage of a 64 x 128 tile are 176 / 192 KiB; with
+  // the highest B slices (9, 10 / 8 .. 11) loaded global -> named VGPRs and refilled in place (slice_gemm_y_tile.h) the B stage
+  // holds 9 / 8 slices: 88 + 72 = 96 + 64 = 160 KiB.  352 / 384 accumulator registers + 88 / 96 of B fragments: the accumulators
+  // are named registers (a[0:255] + v[160:255] / v[128:255]); at 12 slices the compiler is left v[0:95] and the A ring is 2 deep.
+  static constexpr int HYB_WA = 2, HYB_SLB = S == 12 ? 8 : 9;
+  static constexpr bool hyb_ok = S == 11 || S == 12;
   static constexpr size_t HYB_LDS = (size_t)(2 * HYB_WA * 2 * S + 4 * 2 * HYB_SLB) * FRAG_BYTES;
   static_assert(!hyb_ok || (HYB_LDS <= LDS_MAX && !ok), "the hybrid form exists where the LDS form does not fit");
 };
@@ -225,7 +226,7 @@ static hipError_t launch_wide_k64(const SliceGemmArgs &a, const WidePlan &pl, bo
   } else {
     if constexpr (C::breg_ok) {
       if (breg && ((a.kb1 - a.kb0) & 3u) == 0)
-        return launch_wide_kernel<S, ND, C::BREG_WA, VARW_K64 | VARW_BREG, C::DMAE, C::TAIL>(a, pl, C::BREG_LDS, stream);
+        return launch_wide_kernel<S, ND, C::BREG_WA, VARW_K64 | VARW_BREG | VARW_ACCN, C::DMAE, C::TAIL>(a, pl, C::BREG_LDS, stream);
     }
     return launch_wide_kernel<S, ND, C::WA, VARW_K64 | (C::NB == 1 ? VARW_B1 : 0), C::DMAE, C::TAIL>(a, pl, C::LDS, stream);
   }
@@ -277,7 +278,7 @@ static hipError_t launch_wide_multi_k64(const SliceGemmArgs *g, int count, const
   }
   constexpr int WAK = BREG ? C::BREG_WA : C::WA;
   constexpr size_t LDSK = BREG ? C::BREG_LDS : C::LDS;
-  auto kernel = slice_gemm_w_multi_kernel<S, 0, S, WAK, VARW_K64 | (BREG ? VARW_BREG : (C::NB == 1 ? VARW_B1 : 0)), 0, -1, C::DMAE, C::TAIL>;
+  auto kernel = slice_gemm_w_multi_kernel<S, 0, S, WAK, VARW_K64 | (BREG ? (VARW_BREG | VARW_ACCN) : (C::NB == 1 ? VARW_B1 : 0)), 0, -1, C::DMAE, C::TAIL>;
   SliceGemmMulti m{};
   m.count = count;
   uint32_t nb = 0;

@@ -64,25 +64,27 @@ __device__ __forceinline__ void glds16(const int8_t *sbase, uint32_t voff, uint3
                : "memory");
 }
 
-// VARW_BREG (slice_gemm_y_tile.h): the B fragments of the k64 tile live in HAND-ALLOCATED registers v[112:255] (two sets of
+// VARW_BREG (slice_gemm_y_tile.h): the B fragments of the k64 tile live in HAND-ALLOCATED registers v[80:223] (two sets of
 // 2 * S fragments of 4 registers, S <= 9).  hipcc's allocator, handed 36 live 128-bit tuples next to 72 accumulator tuples,
 // splits live ranges between the two parities of the step and spills (1.4 KiB of scratch, hundreds of v_accvgpr copies inside
 // the k loop); named registers cost nothing.  Every asm statement of the k loop that reads or writes them lists the whole
 // range as clobbered, so the compiler keeps no value there across any of them; tests/test_isa_invariants.py checks that no
 // compiler-generated instruction of a BREG kernel touches the range at all.
-#define OZ_BREG_FIRST 112
+#define OZ_BREG_FIRST 80
 #define OZ_BREG_CLOBBERS \
-  "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", \
-  "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", \
-  "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", \
-  "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", \
-  "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", \
-  "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", \
-  "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", \
-  "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", \
-  "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", \
-  "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", \
-  "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+  "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", \
+  "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", \
+  "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", \
+  "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
+  "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", \
+  "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", \
+  "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", \
+  "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", \
+  "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", \
+  "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", \
+  "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", \
+  "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", \
+  "v251", "v252", "v253", "v254", "v255"
 // fragment -> VGPR: lane l loads the 16 bytes at sbase + voff(l) + IMM into v[REG : REG + 3].  Inline asm for the same reason
 // as glds16: the compiler does not count it, the consumer waits with an explicit vmcnt.
 template <int REG, int IMM>
@@ -94,16 +96,21 @@ __device__ __forceinline__ void gload16_named(const int8_t *sbase, uint32_t voff
                : "memory", OZ_BREG_CLOBBERS);
 }
 
-// VARW_ACCN (slice_gemm_y_tile.h): the accumulators of the k64 tile as hand-allocated registers - tuple X < 64 in a[4X : 4X + 3],
-// tuple X >= 64 in v[160 + 4 (X - 64) : ...] (up to 24 tuples: 88 tuples = 11 diagonals on a 64 x 128 tile) - and, with VARW_BHI, the
-// B fragments of the slices j >= 9 in v[144 : 159].  The compiler never sees an accumulator: nothing for its allocator to
-// re-assign between code regions, to copy between the halves of the file or to spill (what it did to every attempt to hold 352
-// accumulator registers - or 288 next to the values of an overlapped epilogue - as C++ variables).  Every asm statement of such a
-// tile lists ALL of these registers as clobbered, so the compiler keeps no value of its own in them across any statement;
-// tests/test_isa_invariants.py checks that no compiler-generated instruction of such a kernel names an AGPR or a VGPR of the range.
-#define OZ_ACCN_V_FIRST 160
-#define OZ_BHI_FIRST 144
-#define OZ_ACCN_CLOBBERS \
+// VARW_ACCN (slice_gemm_y_tile.h): the accumulators of the k64 tile as hand-allocated registers.  The compiler never sees an
+// accumulator: nothing for its allocator to re-assign between code regions, to copy between the halves of the file or to spill
+// (what it did to every attempt to hold 352 accumulator registers - or 288 next to the values of an overlapped epilogue - as C++
+// variables).  Two register plans:
+//   plan 11 (fp64_int8_11, B through LDS + VARW_BHI): tuple X < 64 in a[4X : 4X + 3], X >= 64 in v[160 + 4 (X - 64) ...] (24 tuples),
+//            the in-place B fragments of the slices 9, 10 in v[144:159];
+//   plan 9  (VARW_BREG, 9 diagonals): X < 64 in a[...], the 8 tuples X >= 64 in v[224:255], ABOVE the two B sets v[80:151], v[152:223]:
+//            hipcc hands out VGPRs in ascending order, so what it may use again comes first - the first B set in the overlapped last
+//            step, both sets behind the k loop - and it reaches a live named register only when it needs more than that many
+//            (the first layout had the accumulators at v[80:111], right above its own range: the overlapped step's temporaries
+//            landed in them).
+// Every asm statement of such a tile lists a CLOBBER SET (OZ_CL_*) that contains all named registers alive at that point, so the
+// compiler keeps no value of its own in them across any statement; tests/test_isa_invariants.py checks that no compiler-generated
+// instruction of such a kernel names an AGPR or a VGPR of the plan's range.
+#define OZ_AGPR_ALL \
   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
   "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", \
   "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", \
@@ -121,7 +128,8 @@ __device__ __forceinline__ void gload16_named(const int8_t *sbase, uint32_t voff
   "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
   "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", \
   "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", \
-  "a252", "a253", "a254", "a255", \
+  "a252", "a253", "a254", "a255"
+#define OZ_V144_255 \
   "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", \
   "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", \
   "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", \
@@ -130,58 +138,96 @@ __device__ __forceinline__ void gload16_named(const int8_t *sbase, uint32_t voff
   "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", \
   "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", \
   "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
-template <int REG, int IMM>
+#define OZ_V96_143 \
+  "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", \
+  "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", \
+  "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
+  "v139", "v140", "v141", "v142", "v143"
+#define OZ_V224_255 \
+  "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", \
+  "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", \
+  "v252", "v253", "v254", "v255"
+#define OZ_V80_151 \
+  "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", \
+  "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", \
+  "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", \
+  "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
+  "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151"
+#define OZ_V152_223 \
+  "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", \
+  "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", \
+  "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", \
+  "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", \
+  "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", \
+  "v222", "v223"
+constexpr int OZ_CL_P11 = 0;      // plan 11: a[0:255], v[144:255]
+constexpr int OZ_CL_P9 = 1;       // plan 9:  a[0:255], v[80:255]
+constexpr int OZ_CL_P9_SET1 = 2;  // plan 9, the overlapped last step: the first B set (v[80:151]) is the compiler's again
+constexpr int OZ_CL_P9_ACC = 3;   // plan 9 behind the k loop: the accumulators only (a[0:255], v[224:255])
+constexpr int OZ_CL_P12 = 5;      // plan 12 (fp64_int8_12): a[0:255], v[96:255] - 32 tuples in v[128:255], the in-place B slices 8 .. 11 in v[96:127]
+constexpr int OZ_CL_P11_ACC = 4;  // plan 11 behind the k loop: a[0:255], v[160:255] (= plan 11: v[144:159] are left alone as well)
+__host__ __device__ constexpr int accn_v_first(int cl) { return cl == OZ_CL_P12 ? 128 : (cl == OZ_CL_P11 || cl == OZ_CL_P11_ACC) ? 160 : 224; }
+__host__ __device__ constexpr int accn_bhi_first(int cl) { return cl == OZ_CL_P12 ? 96 : 144; }
+#define OZ_BHI_FIRST 144
+// one asm statement with the clobber set CL (the operand lists are the macro's variadic part: outputs : inputs)
+#define OZ_ACCN_ASM_(CL, MEM, TEXT, ...)                                                        \
+  do {                                                                                          \
+    if constexpr ((CL) == OZ_CL_P11 || (CL) == OZ_CL_P11_ACC)                                   \
+      asm volatile(TEXT : __VA_ARGS__ : MEM OZ_AGPR_ALL, OZ_V144_255);                          \
+    else if constexpr ((CL) == OZ_CL_P12)                                                       \
+      asm volatile(TEXT : __VA_ARGS__ : MEM OZ_AGPR_ALL, OZ_V96_143, OZ_V144_255);              \
+    else if constexpr ((CL) == OZ_CL_P9)                                                        \
+      asm volatile(TEXT : __VA_ARGS__ : MEM OZ_AGPR_ALL, OZ_V80_151, OZ_V152_223, OZ_V224_255); \
+    else if constexpr ((CL) == OZ_CL_P9_SET1)                                                   \
+      asm volatile(TEXT : __VA_ARGS__ : MEM OZ_AGPR_ALL, OZ_V152_223, OZ_V224_255);              \
+    else                                                                                        \
+      asm volatile(TEXT : __VA_ARGS__ : MEM OZ_AGPR_ALL, OZ_V224_255);                           \
+  } while (0)
+#define OZ_ACCN_ASM(CL, TEXT, ...) OZ_ACCN_ASM_(CL, , TEXT, __VA_ARGS__)
+#define OZ_ACCN_ASM_MEM(CL, TEXT, ...) OZ_ACCN_ASM_(CL, "memory" OZ_COMMA, TEXT, __VA_ARGS__)
+#define OZ_COMMA ,
+template <int CL, int REG, int IMM>
 __device__ __forceinline__ void gload16_named_accn(const int8_t *sbase, uint32_t voff) {
-  static_assert(REG >= OZ_BHI_FIRST && REG + 3 < OZ_ACCN_V_FIRST && (REG & 3) == 0, "inside the B range");
-  asm volatile("global_load_dwordx4 v[%c0:%c1], %2, %3 offset:%c4"
-               :
-               : "i"(REG), "i"(REG + 3), "v"(voff), "s"(sbase), "i"(IMM)
-               : "memory", OZ_ACCN_CLOBBERS);
+  static_assert((REG & 3) == 0 && REG >= 80 && REG + 3 <= 223, "inside a B range");
+  OZ_ACCN_ASM_MEM(CL, "global_load_dwordx4 v[%c0:%c1], %2, %3 offset:%c4", : "i"(REG), "i"(REG + 3), "v"(voff), "s"(sbase), "i"(IMM));
 }
 // accumulator tuple X += b x a.  BREG_ < 0: the B fragment is the compiler's value `b`; else v[BREG_ : BREG_ + 3]
-template <int X, int BREG_>
+template <int CL, int X, int BREG_>
 __device__ __forceinline__ void mfma16_accn(const v4i &b, const v4i &a) {
   if constexpr (X < 64) {
     if constexpr (BREG_ < 0)
-      asm volatile("v_mfma_i32_16x16x64_i8 a[%c0:%c1], %2, %3, a[%c0:%c1]" : : "i"(4 * X), "i"(4 * X + 3), "v"(b), "v"(a) : OZ_ACCN_CLOBBERS);
+      OZ_ACCN_ASM(CL, "v_mfma_i32_16x16x64_i8 a[%c0:%c1], %2, %3, a[%c0:%c1]", : "i"(4 * X), "i"(4 * X + 3), "v"(b), "v"(a));
     else
-      asm volatile("v_mfma_i32_16x16x64_i8 a[%c0:%c1], v[%c2:%c3], %4, a[%c0:%c1]"
-                   :
-                   : "i"(4 * X), "i"(4 * X + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a)
-                   : OZ_ACCN_CLOBBERS);
+      OZ_ACCN_ASM(CL, "v_mfma_i32_16x16x64_i8 a[%c0:%c1], v[%c2:%c3], %4, a[%c0:%c1]",
+                  : "i"(4 * X), "i"(4 * X + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a));
   } else {
-    constexpr int V = OZ_ACCN_V_FIRST + 4 * (X - 64);
-    static_assert(V + 3 <= 255, "at most 24 accumulator tuples in the VGPR half");
+    constexpr int V = accn_v_first(CL) + 4 * (X - 64);
+    static_assert(V + 3 <= 255, "accumulator tuples of the VGPR half");
     if constexpr (BREG_ < 0)
-      asm volatile("v_mfma_i32_16x16x64_i8 v[%c0:%c1], %2, %3, v[%c0:%c1]" : : "i"(V), "i"(V + 3), "v"(b), "v"(a) : OZ_ACCN_CLOBBERS);
+      OZ_ACCN_ASM(CL, "v_mfma_i32_16x16x64_i8 v[%c0:%c1], %2, %3, v[%c0:%c1]", : "i"(V), "i"(V + 3), "v"(b), "v"(a));
     else
-      asm volatile("v_mfma_i32_16x16x64_i8 v[%c0:%c1], v[%c2:%c3], %4, v[%c0:%c1]"
-                   :
-                   : "i"(V), "i"(V + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a)
-                   : OZ_ACCN_CLOBBERS);
+      OZ_ACCN_ASM(CL, "v_mfma_i32_16x16x64_i8 v[%c0:%c1], v[%c2:%c3], %4, v[%c0:%c1]",
+                  : "i"(V), "i"(V + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a));
   }
 }
-template <int X>
+template <int CL, int X>
 __device__ __forceinline__ void zero_accn() {
-  if constexpr (X < 64)
-    asm volatile("v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\tv_accvgpr_write_b32 a%c3, 0"
-                 :
-                 : "i"(4 * X), "i"(4 * X + 1), "i"(4 * X + 2), "i"(4 * X + 3)
-                 : OZ_ACCN_CLOBBERS);
-  else
-    asm volatile("v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0\n\tv_mov_b32 v%c2, 0\n\tv_mov_b32 v%c3, 0"
-                 :
-                 : "i"(OZ_ACCN_V_FIRST + 4 * (X - 64)), "i"(OZ_ACCN_V_FIRST + 4 * (X - 64) + 1), "i"(OZ_ACCN_V_FIRST + 4 * (X - 64) + 2),
-                   "i"(OZ_ACCN_V_FIRST + 4 * (X - 64) + 3)
-                 : OZ_ACCN_CLOBBERS);
+  if constexpr (X < 64) {
+    OZ_ACCN_ASM(CL, "v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\tv_accvgpr_write_b32 a%c3, 0",
+                : "i"(4 * X), "i"(4 * X + 1), "i"(4 * X + 2), "i"(4 * X + 3));
+  } else {
+    constexpr int V = accn_v_first(CL) + 4 * (X - 64);
+    OZ_ACCN_ASM(CL, "v_mov_b32 v%c0, 0\n\tv_mov_b32 v%c1, 0\n\tv_mov_b32 v%c2, 0\n\tv_mov_b32 v%c3, 0", : "i"(V), "i"(V + 1), "i"(V + 2), "i"(V + 3));
+  }
 }
 // register v of tuple x -> a compiler value (the epilogue; x, v fold to constants once its loops are unrolled)
+template <int CL>
 __device__ __forceinline__ int read_accn(int x, int v) {
   int r;
   if (x < 64)
-    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "i"(4 * x + v) : OZ_ACCN_CLOBBERS);
+    OZ_ACCN_ASM(CL, "v_accvgpr_read_b32 %0, a%c1", "=v"(r) : "i"(4 * x + v));
   else
-    asm volatile("v_mov_b32 %0, v%c1" : "=v"(r) : "i"(OZ_ACCN_V_FIRST + 4 * (x - 64) + v) : OZ_ACCN_CLOBBERS);
+    OZ_ACCN_ASM(CL, "v_mov_b32 %0, v%c1", "=v"(r) : "i"(accn_v_first(CL) + 4 * (x - 64) + v));
   return r;
 }
 

@@ -102,17 +102,19 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   // next step's first group asks for the new fragment.  (The low slices are needed until the step's last slots: in place they
   // would have a few slots; they keep the LDS round trip, whose reads are issued behind the barrier.)
   constexpr bool ACCN = (VARW & VARW_ACCN) != 0;
-  constexpr int NHI = (VARW & VARW_BHI) ? (SL > 9 ? SL - 9 : 0) : 0;
+  constexpr int NHI = (VARW & VARW_BHI) ? (SL == 12 ? 4 : SL > 9 ? SL - 9 : 0) : 0;
   constexpr int SLB = SL - NHI, KSLB = 2 * SLB; // B slices staged through LDS; their blocks per row-block and step
   static_assert(NHI == 0 || (ACCN && NB == 1 && !BREG), "in-place B slices: named accumulators, one B buffer");
-  static_assert(!ACCN || !BREG, "named accumulators: the LDS form of the tile (the register form keeps its own B sets)");
-  static_assert(NHI * 8 <= OZ_ACCN_V_FIRST - OZ_BHI_FIRST, "v[144:159] hold the in-place fragments");
+  // clobber sets of the tile's asm statements (slice_gemm_w_kernel.h): inside the k loop / behind it
+  constexpr int CLK = BREG ? OZ_CL_P9 : SL == 12 ? OZ_CL_P12 : OZ_CL_P11, CLE = BREG ? OZ_CL_P9_ACC : SL == 12 ? OZ_CL_P12 : OZ_CL_P11_ACC;
+  constexpr int BHI0 = accn_bhi_first(CLK); // first register of the in-place B fragments
+  static_assert(NHI * 8 <= accn_v_first(CLK) - BHI0, "the in-place fragments sit below the accumulators");
   constexpr int A_STAGE = WA * KSL * FRAG_BYTES;
   constexpr int B_STAGE = 4 * KSLB * FRAG_BYTES;
   constexpr int OFF_B = NA * A_STAGE;
   constexpr int NQA = (WA * KSL + 3) / 4;
   constexpr int NDMA = NQA + (BREG ? KSL : KSLB);
-  constexpr int R = RING;
+  constexpr int R = (SL == 12 && (VARW & VARW_ACCN)) ? 2 : RING; // (fp64_int8_12: 480 of 512 registers are operands)
   constexpr int NG = MA * SL;
   constexpr bool NO_GLOBAL = (VARW & (VARW_NO_GLOBAL | VARW_MFMA_ONLY)) != 0;
   constexpr bool MFMA_ONLY = (VARW & VARW_MFMA_ONLY) != 0;
@@ -158,7 +160,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   // VARW_BREG: B fragment (b, j) of step `kstep`, k-group g = lane >> 4, row r = lane & 15: byte
   //   ((2 kstep + (g >> 1)) * S + j) KiB + (g & 1) * 512 + (16 b + r) * 16   of the wave's row-block
   const uint32_t vG = (uint32_t)(((lane >> 4) >> 1) * (S * FRAG_BYTES) + ((lane >> 4) & 1) * 512 + (lane & 15) * 16);
-  static_assert(!BREG || OZ_BREG_FIRST + 16 * SL <= 256, "two register sets of 2 * SL fragments in v[OZ_BREG_FIRST : 255]");
+  static_assert(!BREG || OZ_BREG_FIRST + 16 * SL <= (ACCN ? 224 : 256), "two register sets of 2 * SL fragments in v[OZ_BREG_FIRST : 255]");
   auto load_b = [&](auto cc, uint32_t kstep, auto set) {
     constexpr int c = decltype(cc)::value;          // in the order the next step needs them: j descending, b
     constexpr int j = SL - 1 - c / 2, b = c & 1;
@@ -166,17 +168,20 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     constexpr int REG = OZ_BREG_FIRST + ((decltype(set)::value * 2 + b) * SL + j) * 4;
     if constexpr (!NO_GLOBAL) {
       const uint32_t voff = vG + kstep * (uint32_t)(2 * S * FRAG_BYTES);
-      gload16_named<REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
+      if constexpr (ACCN)
+        gload16_named_accn<CLK, REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
+      else
+        gload16_named<REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
     }
   };
   // VARW_BHI: fragment (b, j >= SLB) of step `kstep` -> v[OZ_BHI_FIRST + ((b * NHI) + j - SLB) * 4 ...], same addressing as load_b
   auto load_hi = [&](auto jc, auto bc, uint32_t kstep) {
     constexpr int j = decltype(jc)::value, b = decltype(bc)::value;
     constexpr int G = 4, g0 = j / G * G;
-    constexpr int REG = OZ_BHI_FIRST + (b * NHI + (j - SLB)) * 4;
+    constexpr int REG = BHI0 + (b * NHI + (j - SLB)) * 4;
     if constexpr (!NO_GLOBAL) {
       const uint32_t voff = vG + kstep * (uint32_t)(2 * S * FRAG_BYTES);
-      gload16_named_accn<REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
+      gload16_named_accn<CLK, REG, (j - g0) * FRAG_BYTES + b * 256>(b_src + g0 * FRAG_BYTES, voff);
     }
   };
   auto copy_n = [&](auto cc, int abuf, int bbuf, uint32_t kstep, auto bnext) { // bnext: register set (VARW_BREG)
@@ -196,10 +201,10 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
 
   // ---- accumulators: MA x 2 x S tuples of 4 registers; the first 64 in the AGPR half ----------------------------
   constexpr int NACC = MA * 2 * ND, NACC_A = ACCN ? 1 : (NACC < 64 ? NACC : 64), NACC_V = (!ACCN && NACC > 64) ? NACC - 64 : 1;
-  static_assert(!ACCN || NACC <= 88, "named accumulators: a[0:255] + v[160:255]");
+  static_assert(!ACCN || NACC <= (BREG ? 72 : SL == 12 ? 96 : 88), "named accumulators: a[0:255] + v[160:255] (register form: + v[80:111])");
   v4i accA[NACC_A], accV[NACC_V];
   if constexpr (ACCN) {
-    static_for<NACC>([&](auto xc) { zero_accn<decltype(xc)::value>(); });
+    static_for<NACC>([&](auto xc) { zero_accn<CLK, decltype(xc)::value>(); });
   } else {
 #pragma unroll
     for (int x = 0; x < NACC_A; x++)
@@ -213,15 +218,17 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   auto mfma = [&](auto xc, const v4i &b, const v4i &a) {
     constexpr int X = decltype(xc)::value;
     if constexpr (ACCN)
-      mfma16_accn<X, -1>(b, a);
+      mfma16_accn<CLK, X, -1>(b, a);
     else if constexpr (X < 64)
       mfma16_agpr(accA[X], b, a);
     else
       mfma16_vgpr(accV[X - 64], b, a);
   };
-  auto mfma_named = [&](auto xc, auto reg, const v4i &a) { // B operand in the named registers (VARW_BREG)
+  auto mfma_named = [&](auto xc, auto reg, const v4i &a, auto cl) { // B operand in the named registers (VARW_BREG)
     constexpr int X = decltype(xc)::value, REG = decltype(reg)::value;
-    if constexpr (X < 64)
+    if constexpr (ACCN)
+      mfma16_accn<decltype(cl)::value, X, REG>(a, a);
+    else if constexpr (X < 64)
       mfma16_agpr_named<REG>(accA[X], a);
     else
       mfma16_vgpr_named<REG>(accV[X - 64], a);
@@ -316,9 +323,102 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   asm volatile("s_nop 7" ::: "memory"); // zero-fill -> first MFMA reading it as C
 
   uint32_t it = 0;
+
+  // ---- the recombination in the shadow of the LAST step's MFMAs (register kernels with named accumulators) -----------------------
+  // The tile boundary of the register kernel IS the FP64 recombination (profiles/r4_ablate/r4l_tile_boundary_...: 3.8 - 4.0 us per
+  // 64 x 128 tile whatever K is: 9 x (v_accvgpr_read + v_cvt_f64_i32 + v_fma_f64) per output with the matrix pipe idle; 11 % of the
+  // kernel at K = 512).  A step walks the 16-row blocks a = 0 .. MA-1 one after the other, so in the last step the accumulators of
+  // block a are final once its MFMAs have issued: their recombination, cut into micro-operations (one diagonal of one column
+  // pair: 2 reads, 2 conversions, 2 fma), is issued BETWEEN the MFMAs of block a + 1 - a wave issues VALU work while the matrix
+  // pipe works off a 16-cycle MFMA - and only the last block's chain is left behind the k loop.  Same operations on every
+  // element in the same order as recombine_and_store16's 16-byte store form: bit-identical.  Interior tiles of a real, final,
+  // single-chunk product with an even ldc and a 16-byte aligned C; every other tile takes the plain last step and epilogue.  The
+  // condition is uniform over the WORKGROUP (the overlapped step has no barrier: the waves must agree on how many they pass).
+  // Round 5 first built this with the accumulators as compiler values: hipcc re-assigned 13 tuples between the k loop and this
+  // step THROUGH SCRATCH (wrong sums, -10 %: profiles/r5_ablate/r5c_*).  With named accumulators there is nothing to re-assign; the
+  // step lists only the second B set as clobbered (OZ_CL_P9_SET1), so the chain's values live in the first set's registers.
+  constexpr int EPU = ND + 3;                 // micro-operations per unit (column pair of a 16 x 16 block): begin, ND diagonals, scale, store
+  constexpr int EPB = 4 * EPU;                // ... per 16-row block: units (b, vp) = 2 column blocks x 2 column pairs
+  constexpr int SPA = NS / MA;                // MFMA slots per 16-row block
+  constexpr int EPI_T0 = 3;                   // first micro-operation this many slots into the next block (XDL write -> VALU read)
+  constexpr bool OVERLAP_BUILT = BREG && ACCN && SL == 9 && !NO_GLOBAL && !MFMA_ONLY && ((VARW >> 8) & 3) == 0 &&
+                                 (VARW & VARW_NO_EPILOGUE) == 0 && SPA * MA == NS && SPA >= EPB + EPI_T0 + 2;
+  const uint32_t e_mu = rb0 * 32u, e_nu = tn * 128u + (uint32_t)wave * 32u;
+  bool overlap = false;
+  if constexpr (OVERLAP_BUILT) {
+    overlap = p.epi_overlap && p.final && !p.cplx && !p.acc_in && e_mu + 16u * MA <= p.M && tn * 128u + 128u <= p.N &&
+              (p.ldc & 1u) == 0 && p.ldc < (1u << 26) && (reinterpret_cast<uintptr_t>(p.c) & 15u) == 0 && nk >= 2;
+#ifdef OZIMMU_HIP_TEST_HOOKS
+    overlap = overlap && !p.dump;
+#endif
+  }
+  double e_sc[OVERLAP_BUILT ? ND : 1], e_ea[OVERLAP_BUILT ? MA : 1], e_eb[OVERLAP_BUILT ? 8 : 1];
+  double e_x0 = 0, e_x1 = 0, e_v0 = 0, e_v1 = 0;
+  double2 e_old[OVERLAP_BUILT ? 4 : 1];
+  uint32_t e_boff = 0;
+  bool e_odd = false, e_rmw = false;
+  auto e_colp = [&](uint32_t cofs, int A) { // wave-uniform: column nu + cofs (+ nl per lane, in e_boff), first row of block A
+    return reinterpret_cast<char *>(p.c + ((size_t)(e_nu + cofs) * p.ldc + e_mu)) + 128 * A;
+  };
+  auto epi_setup = [&]() { // issued a block's worth of MFMAs ahead of the first use: exponents, the old C of block 0
+    const uint32_t nl = 4u * ((uint32_t)lane >> 4);
+    e_odd = (lane & 1) != 0;
+    e_rmw = p.beta != 0.0;
+    e_boff = ((nl + ((uint32_t)lane & 1u)) * (uint32_t)p.ldc + ((uint32_t)lane & 14u)) * 8u;
+#pragma unroll
+    for (int d = 0; d < ND; d++) e_sc[d] = pow2d(46 - p.L * (D0 + d + 2));
+#pragma unroll
+    for (int a = 0; a < MA; a++) e_ea[a] = p.ea[e_mu + ((uint32_t)lane & 15u) + 16 * a];
+    const double *eb_lane = p.eb + e_nu + nl;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) e_eb[4 * b + v] = eb_lane[16 * b + v];
+    if (e_rmw) {
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        e_old[u] = *reinterpret_cast<const double2 *>(e_colp(16 * (u >> 1) + 2 * (u & 1), 0) + (size_t)e_boff);
+    }
+  };
+  // micro-operation m of block A (compile-time indices); CLR: the clobber set of its accumulator reads
+  auto epi_micro = [&](auto a_tag, auto m_tag, auto cl_tag) {
+    constexpr int A = decltype(a_tag)::value, m = decltype(m_tag)::value, CLR = decltype(cl_tag)::value;
+    constexpr int u = m / EPU, q = m % EPU, b = u >> 1, vp = u & 1;
+    constexpr uint32_t cofs = 16 * b + 2 * vp;
+    if constexpr (q == 0) {
+      e_x0 = e_x1 = 0.0;
+    } else if constexpr (q <= ND) {
+      constexpr int d = q - 1, x = (A * 2 + b) * ND + d;
+      e_x0 = fma((double)read_accn<CLR>(x, 2 * vp), e_sc[d], e_x0);
+      e_x1 = fma((double)read_accn<CLR>(x, 2 * vp + 1), e_sc[d], e_x1);
+    } else if constexpr (q == ND + 1) {
+      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
+      e_v0 = e_x0 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp];
+      e_v1 = e_x1 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp + 1];
+    } else {
+      const double s0 = lane_pair_swap(e_v0), s1 = lane_pair_swap(e_v1);
+      double2 y;
+      y.x = e_odd ? s1 : e_v0; // row 2i:     (column n from this lane | column n+1 from the even neighbour)
+      y.y = e_odd ? e_v1 : s0; // row 2i + 1: (column n from the odd neighbour | column n+1 from this lane)
+      char *cp = e_colp(cofs, A) + (size_t)e_boff;
+      if (e_rmw) {
+        y.x = fma(p.alpha, y.x, p.beta * e_old[u].x);
+        y.y = fma(p.alpha, y.y, p.beta * e_old[u].y);
+        if constexpr (A + 1 < MA) // the old values of the next block's unit u: a block's worth of MFMAs ahead of their use
+          e_old[u] = *reinterpret_cast<const double2 *>(e_colp(cofs, A + 1) + (size_t)e_boff);
+      } else {
+        y.x = p.alpha * y.x;
+        y.y = p.alpha * y.y;
+      }
+      *reinterpret_cast<double2 *>(cp) = y;
+    }
+  };
+
   // PAR (VARW_BREG): the register set this step multiplies out of; the next step's fragments are loaded into the other one
-  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag) {
-    constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value;
+  // EPI: the overlapped last step (above)
+  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag, auto epi_tag) {
+    constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value, EPI = decltype(epi_tag)::value;
+    static_assert(!EPI || (!PF && !NX), "the overlapped last step prefetches nothing and meets no barrier");
     constexpr int PC = BREG ? decltype(par_tag)::value : 0, PN = BREG ? (PC ^ 1) : 0;
     const int abuf_n = abuf ^ 1;
     const int abuf_pf = abuf_n, bbuf_pf = NB == 1 ? 0 : (bbuf ^ 1);
@@ -363,11 +463,27 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
         mfma(std::integral_constant<int, X>{}, cf[j], cf[i]);
       else if constexpr (BREG)
         mfma_named(std::integral_constant<int, X>{}, std::integral_constant<int, OZ_BREG_FIRST + ((PC * 2 + b) * SL + j) * 4>{},
-                   g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
+                   g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R], std::integral_constant<int, EPI ? OZ_CL_P9_SET1 : OZ_CL_P9>{});
       else if constexpr (j >= SLB) // VARW_BHI: the fragment in its named registers
-        mfma16_accn<X, OZ_BHI_FIRST + (b * NHI + (j - SLB)) * 4>(af0, g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
+        mfma16_accn<CLK, X, BHI0 + (b * NHI + (j - SLB)) * 4>(af0, g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       else
         mfma(std::integral_constant<int, X>{}, bj[b][j < SLB ? j : 0], g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
+      if constexpr (EPI) {
+        static_assert(PC == 1, "the overlapped step multiplies out of the second register set");
+        if constexpr (s == 1) {
+          epi_setup();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (a >= 1) { // block a - 1 is final: its micro-operations spread over this block's slots
+          constexpr int t = s - a * SPA;
+          static_for<EPB>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (EPI_T0 + m * (SPA - EPI_T0 - 1) / EPB == t)
+              epi_micro(std::integral_constant<int, a - 1>{}, mc, std::integral_constant<int, OZ_CL_P9_SET1>{});
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       if constexpr (PF && NHI > 0) { // the next step's fragment into the registers whose last reader has issued two slots ago
         static_for<2 * NHI>([&](auto cc) {
           constexpr int jh = SLB + decltype(cc)::value / 2, bh = decltype(cc)::value & 1;
@@ -420,24 +536,43 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     // an even number of steps only (slice_gemm_launch.h).
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    using NO = std::false_type;
+    if constexpr (OVERLAP_BUILT) {
+      if (overlap) {
+        for (; it + 2 < nk;) {
+          step(std::true_type{}, std::true_type{}, P0{}, NO{});
+          it++;
+          step(std::true_type{}, std::true_type{}, P1{}, NO{});
+          it++;
+        }
+        step(std::true_type{}, std::true_type{}, P0{}, NO{});
+        it++;
+        step(NO{}, NO{}, P1{}, std::true_type{}); // nothing prefetched, no barrier; blocks 0 .. MA-2 recombined and stored
+        it++;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulators
+        static_for<EPB>([&](auto mc) { epi_micro(std::integral_constant<int, MA - 1>{}, mc, std::integral_constant<int, OZ_CL_P9_ACC>{}); });
+        return;
+      }
+    }
     for (; it < nk;) {
-      step(std::true_type{}, std::true_type{}, P0{});
+      step(std::true_type{}, std::true_type{}, P0{}, NO{});
       it++;
-      step(std::true_type{}, std::true_type{}, P1{});
+      step(std::true_type{}, std::true_type{}, P1{}, NO{});
       it++;
     }
   } else {
     using P0 = std::integral_constant<int, 0>;
-    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{});
+    using NO = std::false_type;
+    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{}, NO{});
     if constexpr (PD > 1)
-      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{});
-    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{});
+      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{}, NO{});
+    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{}, NO{});
   }
 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulator
   auto acc = [&](int a, int b, int d, int v) -> int {
     const int x = (a * 2 + b) * ND + d;
-    if constexpr (ACCN) return read_accn(x, v);
+    if constexpr (ACCN) return read_accn<CLE>(x, v);
     if (x >= 64) return accV[x >= 64 ? x - 64 : 0][v];
     int r;
     asm("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(accA[x < 64 ? x : 0][v]));

@@ -30,8 +30,8 @@ FORCED_ARMS = {
     "k64_breg": {"OZIMMU_HIP_GEMM_KERNEL": "k64", "OZIMMU_HIP_K64_BREG": "1"},
 }
 # a single-pass mode every arm is built for (k64_breg: 9 staged diagonals; x16 at S = 9 is not instantiated: S = 12)
-# (k64 at S = 11: the round-5 form with named accumulator registers and the B slices 9, 10 refilled in place)
-ARM_MODES = {"k2": [4, 9], "classic": [3, 9, 12], "wide": [4, 9, 11], "x16": [12, 10, 11], "k64": [4, 9, 10, 11], "k64_breg": [9]}
+# (k64 at S = 11, 12: the round-5 form with named accumulator registers and the highest B slices refilled in place)
+ARM_MODES = {"k2": [4, 9], "classic": [3, 9, 12], "wide": [4, 9, 11], "x16": [12, 10, 11], "k64": [4, 9, 10, 11, 12], "k64_breg": [9]}
 
 
 def _sync():
@@ -152,7 +152,7 @@ def test_persistent_launch_forms_bit_exact_vs_oracle(oz, monkeypatch, m, n, k, b
 
 
 @pytest.mark.parametrize("grid", [1, 3, 7])
-@pytest.mark.parametrize("arm,S", [("wide", 9), ("wide", 6), ("x16", 12), ("k64", 9), ("k64_breg", 9), ("k64", 6), ("k64", 11)])
+@pytest.mark.parametrize("arm,S", [("wide", 9), ("wide", 6), ("x16", 12), ("k64", 9), ("k64_breg", 9), ("k64", 6), ("k64", 11), ("k64", 12)])
 @pytest.mark.parametrize("m,n,k", [(700, 520, 128), (333, 900, 256)])
 def test_few_persistent_workgroups_walk_many_tiles(oz, monkeypatch, arm, S, m, n, k, grid):
     """OZIMMU_HIP_WIDE_GRID = g on a small problem: the call gets phase lines and claim counters (api.cpp: wants_phase) and g

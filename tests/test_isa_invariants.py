@@ -184,21 +184,64 @@ def test_product_and_test_flavour_kernels_differ_only_in_the_dump_branch():
     assert seen >= 60
 
 
+def _varw(name):     # slice_gemm_w_[multi_]kernel<S, D0, ND, WA, VARW, ...>: the fifth template argument
+    m = re.search(r"kernelILi\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)
+    return int(m.group(1)) if m else 0
+
+
+def _line_vgprs(l):
+    regs = {int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", l)}
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", l):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return regs
+
+
 def test_named_b_registers_are_untouched_by_the_compiler(asm):
-    """VARW_BREG kernels (slice_gemm_y_tile.h) keep the k64 tile's B fragments in hand-allocated registers v[112:255]: the
-    inline-asm loads write them, the inline-asm MFMAs read them, every such statement lists the range as clobbered.  The
-    compiler may use the range before the first load of a tile function and after its last MFMA (the epilogue), never in
-    between - a compiler-generated instruction there (a spill reload, an address temporary) would corrupt a fragment."""
+    """VARW_BREG kernels (slice_gemm_y_tile.h) keep the k64 tile's B fragments in two hand-allocated register sets v[80:151],
+    v[152:223] and (round 5) their accumulators in a[0:255] + v[224:255]: inline-asm loads write the sets, inline-asm MFMAs read
+    them, every statement lists the live named registers as clobbered.  What the compiler may do with them:
+      * AGPRs and v[224:255] (the accumulators): nothing, anywhere;
+      * inside the k loops: nothing above v79;
+      * the first set v[80:151]: free again in the overlapped last step (it multiplies out of the second set and loads nothing) -
+        a compiler-generated instruction may name it only if every MFMA up to the tile's end reads its B operand from the second
+        set and no named load follows;
+      * the second set v[152:223]: only behind the tile's last MFMA (the plain epilogue).
+    (hipcc hands out VGPRs in ascending order: the layout puts what becomes free first right above the compiler's own range.)"""
     ks = {**_kernels(asm["slice_gemm.hip"], "slice_gemm_w_kernel"), **_kernels(asm["slice_gemm.hip"], "slice_gemm_w_multi_kernel")}
-    # (the named-accumulator kernels load their in-place B slices into v[144:159]: their own test below)
-    breg = {n: b for n, b in ks.items() if re.search(r"global_load_dwordx4 v\[11[2-9]:", b)}
+    breg = {n: b for n, b in ks.items() if _varw(n) & 16384}   # VARW_BREG
     assert len(breg) >= 2, "no VARW_BREG kernel in the library"
     for name, body in breg.items():
         lines = body.split("\n")
-        # regions: from a run's first named load to the last MFMA before compiler code touches ... per tile function: the
-        # kernel holds several tile functions (full / reduced height); a region ends at the last MFMA that precedes the
-        # next "first load" (a load preceded by no MFMA since the previous region's end)
-        in_asm, inside, last_mfma, pending = False, False, -1, []
+        for loop in [t for t in _inner_loops(lines) if t.count("v_mfma_i32_16x16x64_i8") >= 20]:
+            in_asm = False
+            for l in loop.split("\n"):
+                if "#ASMSTART" in l:
+                    in_asm = True
+                elif "#ASMEND" in l:
+                    in_asm = False
+                elif not in_asm and not l.strip().startswith(";"):
+                    assert not any(r >= 80 for r in _line_vgprs(l)), f"{name}: compiler code above v79 inside a k loop: {l.strip()}"
+        # per line: what lies between it and the end of its tile function (the next zero-fill of a0, or the kernel's end)
+        in_asm = False
+        kinds = []                      # (index, kind, payload) of the asm instructions: mfma B operand / named load / zero-fill
+        for i, l in enumerate(lines):
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif in_asm:
+                m = re.search(r"v_mfma_i32_16x16x64_i8 [av]\[\d+:\d+\], v\[(\d+):\d+\]", l)
+                if m:
+                    kinds.append((i, "mfma", int(m.group(1))))
+                elif "global_load_dwordx4 v[" in l:
+                    kinds.append((i, "load", 0))
+                elif re.search(r"v_accvgpr_write_b32 a0, 0", l):
+                    kinds.append((i, "zero", 0))
+            elif re.match(r"\s*(s_branch|s_endpgm|s_setpc)", l):
+                kinds.append((i, "zero", 0))   # not fall-through either: the overlapped path leaves the tile function here (the
+                                               # plain k loop that follows in the text is the other side of a branch)
+        assert any("v_accvgpr_write_b32 a0, 0" in l for l in lines), f"{name}: no asm zero-fill (named accumulators expected)"
+        in_asm = False
         for i, l in enumerate(lines):
             if "#ASMSTART" in l:
                 in_asm = True
@@ -206,26 +249,25 @@ def test_named_b_registers_are_untouched_by_the_compiler(asm):
             if "#ASMEND" in l:
                 in_asm = False
                 continue
-            if in_asm:
-                if "global_load_dwordx4 v[" in l:
-                    inside = True
-                if "v_mfma" in l and inside:
-                    last_mfma = i
-                    pending = []          # everything seen so far lies in front of an MFMA of the region: must be clean
+            if in_asm or l.strip().startswith(";"):
                 continue
-            if not inside or l.strip().startswith(";"):
+            assert not re.search(r"\ba\d+\b|\ba\[\d+:\d+\]", l), f"{name}: compiler code names an AGPR: {l.strip()}"
+            regs = _line_vgprs(l)
+            assert not any(r >= 224 for r in regs), f"{name}: compiler code in v[224:255]: {l.strip()}"
+            hi = any(152 <= r <= 223 for r in regs)
+            lo = any(80 <= r <= 151 for r in regs)
+            if not (hi or lo):
                 continue
-            regs = {int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", l)}
-            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", l):
-                regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
-            if any(r >= 112 for r in regs):
-                pending.append((i, l.strip()))
-                # a later MFMA of the same region makes this a violation; the epilogue (no MFMA behind it) may use the range
-                rest = "\n".join(lines[i:i + 4000])
-                nxt_mfma = rest.find("v_mfma")
-                nxt_zero = rest.find("v_accvgpr_write")  # the next tile function starts by zero-filling its accumulators
-                assert nxt_mfma < 0 or (0 <= nxt_zero < nxt_mfma), f"{name}: compiler code touches v112+ inside a k loop: {l.strip()}"
-                inside = False             # epilogue reached: the next named load opens the next region
+            for idx, kind, val in kinds:
+                if idx < i:
+                    continue
+                if kind == "zero":
+                    break
+                if hi:
+                    pytest.fail(f"{name}: compiler code in v[152:223] in front of a named load / MFMA of the same tile: {l.strip()}")
+                if kind == "load":
+                    pytest.fail(f"{name}: compiler code in v[80:151] in front of a named load: {l.strip()}")
+                assert val >= 152, f"{name}: compiler code in v[80:151] in front of an MFMA that reads the first set: {l.strip()}"
 
 
 def test_returning_atomics_are_waited_for_before_their_destination_is_touched(asm):
@@ -275,10 +317,7 @@ def test_named_accumulator_kernels_keep_the_compiler_out_of_their_registers(asm)
     would destroy a sum) nor spill: no compiler-generated instruction names an AGPR or a VGPR >= 144, no scratch, and the kernel
     descriptor gives the wave the whole file (256 + 256)."""
     ks = _kernels(asm["slice_gemm.hip"], "slice_gemm_w_kernel")
-    def varw(name):     # slice_gemm_w_kernel<S, D0, ND, WA, VARW, ...>: the fifth template argument
-        m = re.search(r"kernelILi\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)
-        return int(m.group(1)) if m else 0
-    accn = {n: b for n, b in ks.items() if varw(n) & 32768}   # VARW_ACCN
+    accn = {n: b for n, b in ks.items() if (_varw(n) & 32768) and not (_varw(n) & 16384)}   # VARW_ACCN
     assert len(accn) >= 1, "no named-accumulator kernel in the library"
     for name, body in accn.items():
         assert "scratch_" not in body, name

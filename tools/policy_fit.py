@@ -197,8 +197,8 @@ def fit(args):
         return np.array(res)
 
     #     K2 a beta f step       CL a a1 beta b f step               CL4 a step    W / X / Y / Z: a beta b step             wide_f gamma epi_w epi_y   C/MB
-    lo = [0.3, 0.0, 0.0, 0.0] + [0.3, 0.3, 0.0, 0.0, 0.0, 0.0] + [0.3, 0.0] + [0.3, 0.0, 0.0, 0.0] * 4 + [0.0, 0.55, 0.0, 0.0] + [0.0] + [0.0, 0.0]
-    hi = [4.0, 5.0, 40., 2.0] + [4.0, 4.0, 5.0, 40., 40., 2.0] + [4.0, 2.0] + [4.0, 5.0, 40., 2.0] * 4 + [40., 1.0, 3.0, 3.0] + [2.0] + [1.0, 5.0]
+    lo = [0.3, 0.0, 0.0, 0.0] + [0.3, 0.3, 0.0, 0.0, 0.0, 0.0] + [0.3, 0.0] + [0.3, 0.0, 0.0, 0.0] * 4 + [0.0, 0.55, 0.0, 0.0] + [0.0] + [0.0, 0.0] + [0.0, 0.0, 0.0]
+    hi = [4.0, 5.0, 40., 2.0] + [4.0, 4.0, 5.0, 40., 40., 2.0] + [4.0, 2.0] + [4.0, 5.0, 40., 2.0] * 4 + [40., 1.0, 3.0, 3.0] + [2.0] + [1.0, 5.0] + [1.0, 2.0, 10.0]
     nfit = len(lo)
     sol = least_squares(resid, np.clip(p0[:nfit], lo, hi), bounds=(lo, hi), loss="soft_l1", f_scale=0.1, diff_step=1e-3)
     # second stage: the constants decide a CHOICE, so what counts is the time of the kernel they pick.  Smooth surrogate of the
@@ -235,14 +235,14 @@ def fit(args):
     r = resid(sol.x)
     print(f"fit: {len(r)} measurements, rms log error {float(np.sqrt((r ** 2).mean())):.4f}, median |err| {float(np.median(np.abs(r))) * 100:.1f} %")
     names = ["K2 a, beta, f, step", "CL a, a1, beta, b, f, step", "CL4 a, step", "W a, beta, b, step", "X a, beta, b, step",
-             "Y a, beta, b, step", "Z a, beta, b, step", "wide f, gamma, epi_w, epi_y", "C us per MB", "cl drift, store per block"]
-    sizes = [4, 6, 2, 4, 4, 4, 4, 4, 1, 2]
+             "Y a, beta, b, step", "Z a, beta, b, step", "wide f, gamma, epi_w, epi_y", "C us per MB", "cl drift, store per block", "cl epi, cl C us per MB, cl round"]
+    sizes = [4, 6, 2, 4, 4, 4, 4, 4, 1, 2, 3]
     i = 0
     print("static double g_params[POLICY_PARAMS] = {")
     for nm, sz in zip(names, sizes):
         print(f"    /* {nm:22s} */ " + ", ".join(f"{v:.4g}" for v in sol.x[i:i + sz]) + ",")
         i += sz
-    print("    0, 0, 0, 0.0, 0.0};")
+    print("    0.0, 0.0};")
     summ = regret_summary(oz, rows)
     print("regret with the fitted constants:", json.dumps(summ, indent=1))
     if args.validate:
