@@ -13,14 +13,16 @@ namespace ozhip {
 // tile: (h + 4) SL / (4 h pairs) for a wide tile of h blocks x 128 columns, SL / pairs for the 64 x 64 tiles.
 //   tile time   = blocks per wave x w x (a + beta x rho) + b          [us]
 //   kernel time = f + makespan of the tiles on the CUs
-// Fitted by tools/policy_fit.py to the times of every forced kernel on 750 random shapes x S in {4, 6, 8, 9, 10, 12} (profiles/
-// r4_policy/policy_q_seed{0,1,2}.jsonl: whole QUEUED calls - the steady state of a power-limited part, not single calls on a
-// cool one - with the split time, the same for every kernel, measured next to them; least squares on log((predicted + split)
-// / measured), then a few Powell sweeps on a smooth surrogate of the regret, anchored to the fit error; held out: seed 3, 250
-// cases).  Regret of the resulting choice = time of the call with the picked kernel / with the best measured one - 1: mean
-// 0.40 % (held out 0.28 %), 95 % (97 %) of the cases within 3 %, worst 11 % (9.6 %): very large outputs at K = 256, where the
-// model still prefers the 64 x 64 tiles.  `ozimmu_hip_policy_params` reads / replaces the table at run time (the fit's own
-// loop; a box whose constants differ can be refitted without a rebuild).
+// Fitted by tools/policy_fit.py to the times of every forced kernel (whole QUEUED calls - the steady state of a power-limited part -
+// with the split time, the same for every kernel, measured next to them; least squares on log((predicted + split) / measured),
+// then a few Powell sweeps on a smooth surrogate of the regret).  Round 5 refit: the kernels changed (fp64_int8_11 / 12 on the k64
+// tile, the register kernel's recombination under its last step), so the data is this round's - 430 shapes x S in {4 .. 12} incl.
+// 80 short-K panels under 4096^2 .. 32768^2 outputs (profiles/r5_policy/policy_q2_*) + the round-4 rows of the modes whose kernels
+// did not change.  Regret of the resulting choice (time with the picked kernel / with the best measured one - 1): mean 0.56 %,
+// 93 % of the cases within 3 % on the fit data and on 200 held-out cases alike (round-4 constants on the same data: 0.71 %, 92 %);
+// what is left is k loops of <= 16 k-blocks, where kernels differ by less than the model's 11 % rms error and a per-class bias
+// table fitted to the residuals changes nothing (the misses are shape-specific, not systematic).  `ozimmu_hip_policy_params`
+// reads / replaces the table at run time.
 enum : int {
   K2_A, K2_BETA, K2_F, K2_STEP,
   CL_A, CL_A1, CL_BETA, CL_B, CL_F, CL_STEP, CL4_A, CL4_STEP,
@@ -48,18 +50,17 @@ static_assert(DEV_MFMA_US + 1 == POLICY_PARAMS, "parameter table");
 // and this term is what separates the kernels.
 
 static double g_params[POLICY_PARAMS] = {
-    /* K2  a, beta, f, step           */ 1.158, 0, 0, 0,
-    /* CL  a, a1, beta, b, f, step    */ 0.9613, 1.236, 0, 0, 0, 0.1475,
-    /* CL4 a, step                    */ 0.7253, 1.604,
-    /* W   a, beta, b, step           */ 0.8483, 0.6041, 1.023, 0.2076,
-    /* X   a, beta, b, step           */ 0.6933, 0, 0.4371, 0.546,
-    /* Y   a, beta, b, step           */ 0.6667, 0.03812, 2.226, 0.466,
-    /* Z   a, beta, b, step           */ 0.712, 0, 2.376, 0,
-    /* wide f, gamma, epi_w, epi_y    */ 1.681, 0.7697, 0.08047, 0.09886,
-    /* C us per MB                    */ 0.1775,
-    /* cl drift, store per block      */ 0, 0.7782,
-    /* cl epi, cl C us per MB */ 0, 0.1775,
-    /* cl round */ 0,
+    /* K2  a, beta, f, step           */ 1.115, 0, 0, 0,
+    /* CL  a, a1, beta, b, f, step    */ 1.023, 1.27, 0, 0, 0, 0.107,
+    /* CL4 a, step                    */ 0.9487, 0.6612,
+    /* W   a, beta, b, step           */ 0.835, 0.1284, 0, 0.3188,
+    /* X   a, beta, b, step           */ 0.7832, 0, 1.144, 0.4425,
+    /* Y   a, beta, b, step           */ 0.6964, 0.02605, 1.986, 0.4175,
+    /* Z   a, beta, b, step           */ 0.7466, 0, 5.304, 0,
+    /* wide f, gamma, epi_w, epi_y    */ 1.1, 0.7485, 0.1655, 0.1439,
+    /* C us per MB                    */ 0.1323,
+    /* cl drift, store per block      */ 0, 0.9538,
+    /* cl epi, cl C us per MB, round  */ 0.09293, 0, 3.513,
     0.0, 0.0};
 
 static std::mutex g_params_mtx;
