@@ -198,7 +198,8 @@ def device_info(handle):
     return {"cus": int(v[0]), "xcds": int(v[1]), "mfma32_us": v[2], "mfma32_measured_us": v[3]}
 
 
-KERNEL_NAMES = {0: "k2", 1: "classic", 2: "wide", 3: "x16", 4: "k64", 12: "k64_breg", -1: None}
+# (16 = k2_one_launch: the K-split tile behind the split of the same call in ONE kernel, csrc/slice_gemm_one_launch.hip)
+KERNEL_NAMES = {0: "k2", 1: "classic", 2: "wide", 3: "x16", 4: "k64", 12: "k64_breg", 16: "k2_one_launch", -1: None}
 POLICY_PARAMS = 40
 
 

@@ -12,6 +12,7 @@ The .so is git-ignored but travels with the tree (gpurun snapshot); nothing is i
 """
 import concurrent.futures
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -21,9 +22,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libozimmu_hip.so")
 LIB_TEST = os.path.join(HERE, "libozimmu_hip_test.so")
 GEMM_PARTS = ["slice_gemm_s3_4.hip", "slice_gemm_s5_6.hip", "slice_gemm_s7_7.hip", "slice_gemm_s8_8.hip", "slice_gemm_s9_9.hip", "slice_gemm_s10_10.hip", "slice_gemm_s11_11.hip", "slice_gemm_s12_12.hip", "slice_gemm_s13_13.hip", "slice_gemm_s14_14.hip", "slice_gemm_s15_15.hip", "slice_gemm_s16_16.hip", "slice_gemm_s17_17.hip", "slice_gemm_s18_18.hip"]
-SOURCES = GEMM_PARTS + ["slice_gemm.hip", "topology.hip", "split.hip", "convert.hip", "api.cpp", "config.cpp", "kernel_policy.cpp", "interpose.cpp"]
+SOURCES = GEMM_PARTS + ["slice_gemm.hip", "slice_gemm_one_launch.hip", "topology.hip", "split.hip", "convert.hip", "api.cpp", "config.cpp", "kernel_policy.cpp", "interpose.cpp"]
 HEADERS = ["kernels.h", "config.h", "topology.h", "tile_plan.h", "kernel_policy.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", "slice_gemm_x_tile.h", "slice_gemm_y_tile.h", "slice_gemm_k2_kernel.h",
-           "slice_gemm_launch.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
+           "slice_gemm_launch.h", "split_resident.h", "one_launch.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
 ARCH = "gfx950"
 
 
@@ -39,6 +40,23 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _closure(path, seen=None):
+    """the file and every project header it includes, transitively: an object is stale when one of THESE is newer (a slice-GEMM
+    unit takes minutes; a change of split_resident.h or api.cpp must not recompile all fourteen of them)"""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as f:
+        for inc in _INCLUDE.findall(f.read()):
+            _closure(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
 
 
 def device_asm_path(source):
@@ -77,16 +95,20 @@ def build(force=False, verbose=False, test_flavour=True, product=True):
     """compiles the stale translation units of both flavours side by side (the slice-GEMM parts take minutes each), links
     libozimmu_hip.so (the product) and libozimmu_hip_test.so (with the test hooks); returns the product's path"""
     hipcc = _hipcc()
-    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, h) for h in HEADERS]  # (compiler flags live in this file: after changing them, --force)
     flavours = [_flavour(h) for h in ([False] if product else []) + ([True] if test_flavour else [])]
     jobs = []
     all_src = [os.path.join(CSRC, s) for s in SOURCES] + deps
     # a library newer than every source is current even where its objects are absent (the GPU box: build/ and build_test/ -
     # objects and kept assembly, 200 MB - are listed in .gpurunignore and do not travel with the snapshot)
-    flavours = [f for f in flavours if force or _stale(f[3], all_src)]
+    # ... but where the object directory is present (a development box), a missing or outdated object means the library is too
+    def _objects_stale(bdir, objs):
+        return os.path.isdir(os.path.join(HERE, bdir)) and any(
+            _stale(obj, sorted(_closure(os.path.join(CSRC, s)))) for s, obj in zip(SOURCES, objs))
+    flavours = [f for f in flavours if force or _stale(f[3], all_src) or _objects_stale(f[0], f[2])]
     for bdir, common, objs, _ in flavours:
         os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
-        jobs += [(common, s, bdir) for s, obj in zip(SOURCES, objs) if force or _stale(obj, [os.path.join(CSRC, s)] + deps)]
+        jobs += [(common, s, bdir) for s, obj in zip(SOURCES, objs) if force or _stale(obj, sorted(_closure(os.path.join(CSRC, s))))]
     jobs.sort(key=lambda j: j[1] not in GEMM_PARTS)  # the long ones first
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
         for f in [pool.submit(_compile, hipcc, common, s, verbose, bdir) for common, s, bdir in jobs]:

@@ -22,7 +22,9 @@ pytestmark = pytest.mark.gpu
 
 # name reported by ozimmu_hip_last_kernel -> the switches that force it (on a shape / mode where the kernel exists)
 FORCED_ARMS = {
-    "k2": {"OZIMMU_HIP_GEMM_KERNEL": "k2"},
+    "k2": {"OZIMMU_HIP_GEMM_KERNEL": "k2", "OZIMMU_HIP_ONE_LAUNCH": "0"},
+    # split + K-split tile in ONE kernel (csrc/slice_gemm_one_launch.hip): what a small real GEMM (K <= 2048, S <= 9) runs by default
+    "k2_one_launch": {"OZIMMU_HIP_GEMM_KERNEL": "k2", "OZIMMU_HIP_ONE_LAUNCH": "1"},
     "classic": {"OZIMMU_HIP_GEMM_KERNEL": "classic"},
     "wide": {"OZIMMU_HIP_GEMM_KERNEL": "wide", "OZIMMU_HIP_PAIRED_TILE": "0"},
     "x16": {"OZIMMU_HIP_GEMM_KERNEL": "x16"},
@@ -31,7 +33,7 @@ FORCED_ARMS = {
 }
 # a single-pass mode every arm is built for (k64_breg: 9 staged diagonals; x16 at S = 9 is not instantiated: S = 12)
 # (k64 at S = 11, 12: the round-5 form with named accumulator registers and the highest B slices refilled in place)
-ARM_MODES = {"k2": [4, 9], "classic": [3, 9, 12], "wide": [4, 9, 11], "x16": [12, 10, 11], "k64": [4, 9, 10, 11, 12], "k64_breg": [9]}
+ARM_MODES = {"k2": [4, 9], "k2_one_launch": [3, 4, 7, 9], "classic": [3, 9, 12], "wide": [4, 9, 11], "x16": [12, 10, 11], "k64": [4, 9, 10, 11, 12], "k64_breg": [9]}
 
 
 def _sync():
@@ -40,7 +42,7 @@ def _sync():
 
 
 def _force(monkeypatch, arm, **extra):
-    for k in ("OZIMMU_HIP_GEMM_KERNEL", "OZIMMU_HIP_PAIRED_TILE", "OZIMMU_HIP_K64_BREG", "OZIMMU_HIP_K64_TILE"):
+    for k in ("OZIMMU_HIP_GEMM_KERNEL", "OZIMMU_HIP_PAIRED_TILE", "OZIMMU_HIP_K64_BREG", "OZIMMU_HIP_K64_TILE", "OZIMMU_HIP_ONE_LAUNCH"):
         monkeypatch.delenv(k, raising=False)
     for k, v in {**FORCED_ARMS[arm], **extra}.items():
         monkeypatch.setenv(k, str(v))

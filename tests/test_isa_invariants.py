@@ -342,3 +342,37 @@ def test_named_accumulator_kernels_keep_the_compiler_out_of_their_registers(asm)
         assert mfmas >= 1000, (name, mfmas)
         meta = re.search(re.escape(name) + r"\.kd.*?\.vgpr_count:\s+(\d+)", asm["slice_gemm.hip"], flags=re.S)
         assert meta and int(meta.group(1)) == 512, name
+
+
+def test_one_launch_kernel_uses_no_cache_maintenance_and_no_scratch(tmp_path):
+    """slice_gemm_one_launch.hip hands slice planes from producer to consumer workgroups INSIDE one kernel without flushing or
+    invalidating a cache (its header: "Visibility"): the producers' stores must be write-through (sc0 sc1), the READY words
+    must be read and written at agent scope (sc1), and the compiler must not have added buffer_wbl2 / buffer_inv (a fence that
+    crept back in costs a full-L2 operation per workgroup: measured 84 instead of 37 us) - nor scratch."""
+    sys.path.insert(0, ROOT)
+    from ozimmu_amd import build as B
+    src = "slice_gemm_one_launch.hip"
+    kept = B.device_asm_path(src)
+    deps = sorted(B._closure(os.path.join(CSRC, src)))
+    if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(f) for f in deps):
+        text = open(kept).read()
+    else:
+        o = tmp_path / "one_launch.s"
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC, "-D__HIP_PLATFORM_AMD__",
+                               "-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", str(o)])
+        text = o.read_text()
+    kernels = re.findall(r"^(_ZN5ozhip20split_gemm_k2_kernelILi(\d+)E\w*):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M)
+    assert sorted(int(k[1]) for k in kernels) == list(range(3, 10))
+    for name, S, body in kernels:
+        assert "buffer_wbl2" not in body and "buffer_inv" not in body, name
+        assert "scratch_" not in body, name
+        stores = re.findall(r"global_store_dwordx4 .*", body)
+        # every 16-byte store of the split phase is write-through; the epilogue stores C with dwordx2 / dwordx4 without sc bits
+        wt = [l for l in stores if "sc0 sc1" in l]
+        assert len(wt) >= 2, (name, len(wt))                       # one per operand layout
+        assert re.search(r"global_store_dwordx2 .* sc0 sc1", body), name   # the row scales
+        assert re.search(r"global_load_dword v\d+, .* sc1", body), name    # the READY poll
+        assert re.search(r"global_store_dword v\d+, .* sc1", body), name   # the READY store
+        assert "v_mfma_i32_32x32x32_i8" in body, name
+    meta = re.findall(r"\.name:\s+_ZN5ozhip20split_gemm_k2_kernel\w+\n(?:.*\n)*?\s+\.private_segment_fixed_size: (\d+)", text)
+    assert meta and all(int(x) == 0 for x in meta)
