@@ -307,13 +307,16 @@ __global__ __launch_bounds__(256) void cut_kernel(const double *__restrict__ in,
                                                   size_t sr, size_t sk, const uint32_t *__restrict__ exps, int S, int L,
                                                   int8_t *__restrict__ planes, double *__restrict__ max_exp,
                                                   size_t RB, size_t KB, int strip, long long in_stride,
-                                                  size_t ws_stride, size_t exps_stride, uint32_t tag) {
+                                                  size_t ws_stride, size_t exps_stride, uint32_t tag, int reverse) {
   __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
   in += (long long)blockIdx.z * in_stride; // batch (kernels.h: Batch)
   exps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(exps) + (size_t)blockIdx.z * exps_stride);
   planes += (size_t)blockIdx.z * ws_stride;
   max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(max_exp) + (size_t)blockIdx.z * ws_stride);
-  cut_body<KCONTIG, PREFETCH, LOW>(in, rows, K, sr, sk, exps, S, L, planes, max_exp, RB, KB, strip, blockIdx.x, tiles, tag);
+  // reverse: walk the operand from its END.  Both passes walk memory in ascending order by workgroup index; the row-maximum
+  // pass has just streamed the operand through the 256 MiB memory-side cache, so what it read LAST is what is still there.
+  const size_t block = reverse ? (size_t)(gridDim.x - 1u - blockIdx.x) : (size_t)blockIdx.x;
+  cut_body<KCONTIG, PREFETCH, LOW>(in, rows, K, sr, sk, exps, S, L, planes, max_exp, RB, KB, strip, block, tiles, tag);
 }
 
 // up to 4 operand views per launch (see row_max_kernel): the form for small problems
@@ -400,6 +403,17 @@ hipError_t launch_cut_multi(const SplitJob *job, int count, int S, int L, hipStr
   return hipGetLastError();
 }
 
+// OZIMMU_HIP_SPLIT_REVERSE (development switch, read like those of config.h): 0 = the cut pass walks the operand from its start
+static bool cut_reverse() {
+  auto read = []() {
+    const char *e = counted_getenv("OZIMMU_HIP_SPLIT_REVERSE");
+    return !(e && e[0] == '0');
+  };
+  if (config().env_per_call) return read();
+  static const bool r = read();
+  return r;
+}
+
 hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, int8_t *planes,
                       double *max_exp, hipStream_t stream, const Batch &b) {
   const size_t RB = row_blocks_padded(v.rows), KB = k_blocks(v.K);
@@ -409,21 +423,22 @@ hipError_t launch_cut(const OperandView &v, const uint32_t *exps, int S, int L, 
   const size_t strips = ((kcontig ? KB : RB) + strip - 1) / strip * (kcontig ? RB : KB);
   const dim3 grid((unsigned)((strips + 3) / 4), 1, b.count);
   const bool low = S * L > 64; // some slice reaches into the lower 64 bits of the shifted mantissa
+  const int rev = cut_reverse() ? 1 : 0;
   if (kcontig && strip == 1 && low) // no strip to prefetch along: the register-lean form (4 waves per SIMD instead of 2)
     hipLaunchKernelGGL((cut_kernel<true, false, true>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag, rev);
   else if (kcontig && strip == 1)
     hipLaunchKernelGGL((cut_kernel<true, false, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag, rev);
   else if (kcontig)
     hipLaunchKernelGGL(cut_kernel<true>, grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag, rev);
   else if (low)
     hipLaunchKernelGGL((cut_kernel<false, false, true>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag, rev);
   else
     hipLaunchKernelGGL((cut_kernel<false, false, false>), grid, dim3(256), 0, stream, v.in, v.rows, v.K, v.stride_r, v.stride_k,
-                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag);
+                       exps, S, L, planes, max_exp, RB, KB, strip, b.in_stride, b.ws_stride, b.exps_stride, b.tag, rev);
   return hipGetLastError();
 }
 

@@ -35,6 +35,9 @@ def split_kernel(request, monkeypatch):
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_MULTI_BYTES", "0")
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_BAND_BYTES", "65536")
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_STRIP", "3")  # the k-contiguous cut's strip + prefetch form (A/B switch)
+        # the per-view cut pass walks the operand from its end by default (split.hip: cut_kernel); half of the cases from its start
+        import zlib
+        monkeypatch.setenv("OZIMMU_HIP_SPLIT_REVERSE", str(zlib.crc32(request.node.name.encode()) & 1))
     elif request.param == "one_pass_split":
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_ONE_PASS_BYTES", str(1 << 40))
 
