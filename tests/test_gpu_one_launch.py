@@ -54,15 +54,16 @@ def test_one_launch_gemm_bit_exact_vs_oracle(oz, monkeypatch, op_a, op_b, m, n, 
     assert kernel == ("k2_one_launch" if pick == "k2" else pick)
 
 
-@pytest.mark.parametrize("m,n,k", [(768, 768, 768), (1024, 1024, 512), (640, 640, 640)])
+@pytest.mark.parametrize("m,n,k", [(512, 512, 512), (1024, 1024, 512), (640, 640, 640)])
 def test_one_launch_is_the_default_where_the_policy_picks_the_k_split_tile(oz, monkeypatch, m, n, k):
     """no switch set: problems of at most one 64 x 64 tile per CU whose K loop the cost model gives to the K-split tile run
     split + GEMM as one kernel (1024^3 itself goes to the k64 register kernel, two launches: profiles/r5_ablate/r5h_*)"""
     m_, h = oz
     for kname in ("OZIMMU_HIP_GEMM_KERNEL", "OZIMMU_HIP_ONE_LAUNCH", "OZIMMU_HIP_SPLIT_RESIDENT"):
         monkeypatch.delenv(kname, raising=False)
-    assert m_.policy_predict(h, 9, m, n, k)[1] == "k2"
-    assert _run(m_, h, "N", "N", m, n, k, 9, np.random.default_rng(5)) == "k2_one_launch"
+    pick = m_.policy_predict(h, 9, m, n, k)[1]   # (follows the device's measured MFMA time: 768^3 goes either way from box to box)
+    assert _run(m_, h, "N", "N", m, n, k, 9, np.random.default_rng(5)) == ("k2_one_launch" if pick == "k2" else pick)
+    assert pick == "k2"
 
 
 @pytest.mark.parametrize("spin", [1, 3])

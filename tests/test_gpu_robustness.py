@@ -550,7 +550,8 @@ def test_the_policy_runs_what_it_predicts_and_reports_it(oz, monkeypatch):
         torch.cuda.synchronize()
         ran = m_.last_kernel(h)
         pred, pick = m_.policy_predict(h, S, m, n, k)
-        assert ran[0] == pick and pick == min(pred, key=pred.get), (ran, pick, pred)
+        # (a small real GEMM on the K-split tile cuts its strips in the same launch: "k2_one_launch", the cost model's "k2")
+        assert ran[0].replace("_one_launch", "") == pick and pick == min(pred, key=pred.get), (ran, pick, pred)
         assert (ran[1] is None) == (S <= 12)
         monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", "classic")
         assert m_.gemm(h, "N", "N", m, n, k, 1.0, a, m, b, k, 0.0, c, m, f"fp64_int8_{S}") == 0
