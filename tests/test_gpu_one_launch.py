@@ -142,3 +142,42 @@ def test_one_launch_diagonal_sums_bit_exact(ozh, monkeypatch, S):
     _sync()
     assert m_.last_kernel(h)[0] == "k2_one_launch"
     np.testing.assert_array_equal(out.cpu().numpy().transpose(0, 2, 1).astype(np.int64), O.diagonal_sums(pa, pb))
+
+
+def test_one_launch_equals_two_launches_under_churn(oz, monkeypatch):
+    """Stress of the visibility protocol (slice_gemm_one_launch.hip: write-through producers, no cache maintenance): many
+    calls in a row on ONE handle - same workspace addresses, fresh random operands of changing shape and layout every time, no
+    host synchronisation between the one-launch call and its two-launch twin - every result compared bit for bit with the
+    two-launch form of the same product.  A stale cache line of an earlier call, a READY word seen too early or a torn strip
+    shows up as a mismatch.  OZIMMU_ONE_LAUNCH_STRESS=n runs n rounds (default 300; profiles/r5_ablate/r5k_*: 20 000)."""
+    import os
+    import torch
+    m_, h = oz
+    monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", "k2")
+    rounds = int(os.environ.get("OZIMMU_ONE_LAUNCH_STRESS", "300"))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    rng = np.random.default_rng(77)
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")   # counted on the device: the calls queue back to back
+    for it in range(rounds):
+        m, n = (int(rng.integers(1, 1025)) for _ in range(2))
+        k = int(rng.choice([32, 96, 128, 200, 256, 512, 777, 1024, 1536, 2048]))
+        S = int(rng.choice([3, 6, 8, 9]))
+        op_a, op_b = rng.choice(["N", "T"]), rng.choice(["N", "T"])
+        scale = float(rng.choice([1.0, 1e-3, 1e5]))
+        a = (torch.rand((k, m) if op_a == "N" else (m, k), dtype=torch.float64, device="cuda", generator=g) - 0.5) * scale
+        b = (torch.rand((n, k) if op_b == "N" else (k, n), dtype=torch.float64, device="cuda", generator=g) - 0.5)
+        lda, ldb = a.shape[1], b.shape[1]
+        c0 = torch.rand((n, m), dtype=torch.float64, device="cuda", generator=g)
+        c1, c2 = c0.clone(), c0.clone()
+        monkeypatch.setenv("OZIMMU_HIP_ONE_LAUNCH", "1")
+        assert m_.gemm(h, op_a, op_b, m, n, k, 1.25, a, lda, b, ldb, -0.5, c1, m, f"fp64_int8_{S}") == 0
+        ran = m_.last_kernel(h)[0]
+        monkeypatch.setenv("OZIMMU_HIP_ONE_LAUNCH", "0")
+        assert m_.gemm(h, op_a, op_b, m, n, k, 1.25, a, lda, b, ldb, -0.5, c2, m, f"fp64_int8_{S}") == 0
+        assert ran == "k2_one_launch" and m_.last_kernel(h)[0] == "k2"
+        bad += (c1.view(torch.int64) != c2.view(torch.int64)).any().to(torch.int64)
+        if it % 50 == 49:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, f"{int(bad)} of {rounds} one-launch results differ from the two-launch form"
