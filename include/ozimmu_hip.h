@@ -118,6 +118,13 @@ int ozimmu_hip_device_topology(int device, double inout[4], int set);
 int ozimmu_hip_policy_predict_device(int device, int num_split, int pass, size_t m, size_t n, size_t k, size_t batch,
                                      double out_us[6], int *pick);
 int ozimmu_hip_last_kernel(ozimmu_hip_handle_t handle, int out[2]);
+/* Measured kernel choice (csrc/kernel_tuner.h; no counterpart in the reference, whose GEMMs cuBLAS plans): a plain real GEMM
+ * whose (mode, m, n, k) the handle has seen before runs, in turn, the kernels the model predicts within 25 % (K <= 512; 12 % up to K = 2048) of its best - all
+ * of them return the same bits - each call bracketed by two events on the caller's stream, and keeps the fastest once four
+ * rounds of times (the first one discarded) are in (no synchronisation: finished event pairs are collected by later calls).  OZIMMU_HIP_AUTOTUNE=0
+ * switches it off.  ozimmu_hip_tuner_state: -1 = shape unknown to this handle, 0 = still measuring, 1 = decided;
+ * out[0] = prediction slot (0..5, as in ozimmu_hip_policy_predict) of the decided kernel or -1, out[1] = candidates. */
+int ozimmu_hip_tuner_state(ozimmu_hip_handle_t handle, int num_split, size_t m, size_t n, size_t k, int out[2]);
 int ozimmu_hip_destroy(ozimmu_hip_handle_t handle);
 
 /* ozimmu.hpp:50-51 set_cuda_stream (src/handle.cu:54-61). `hip_stream` is a hipStream_t. */

@@ -234,6 +234,18 @@ def last_kernel(handle):
     return [KERNEL_NAMES.get(v[0], str(v[0])), KERNEL_NAMES.get(v[1], str(v[1]))]
 
 
+def tuner_state(handle, mode, m, n, k):
+    """measured kernel choice of this handle for a plain real GEMM shape: (state, slot, candidates); state -1 = unknown shape,
+    0 = still measuring, 1 = decided on prediction slot `slot` (index into KERNELS of policy_predict)"""
+    v = (C.c_int * 2)()
+    L = lib()
+    L.ozimmu_hip_tuner_state.restype = C.c_int
+    L.ozimmu_hip_tuner_state.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    S = int(str(mode).rsplit("_", 1)[1])
+    st = L.ozimmu_hip_tuner_state(handle.ptr, S, m, n, k, v)
+    return st, v[0], v[1]
+
+
 def set_auto_mantissa_loss_threashold(handle, threshold):
     lib().ozimmu_hip_set_auto_mantissa_loss_threashold(handle.ptr, float(threshold))
 

@@ -22,8 +22,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libozimmu_hip.so")
 LIB_TEST = os.path.join(HERE, "libozimmu_hip_test.so")
 GEMM_PARTS = ["slice_gemm_s3_4.hip", "slice_gemm_s5_6.hip", "slice_gemm_s7_7.hip", "slice_gemm_s8_8.hip", "slice_gemm_s9_9.hip", "slice_gemm_s10_10.hip", "slice_gemm_s11_11.hip", "slice_gemm_s12_12.hip", "slice_gemm_s13_13.hip", "slice_gemm_s14_14.hip", "slice_gemm_s15_15.hip", "slice_gemm_s16_16.hip", "slice_gemm_s17_17.hip", "slice_gemm_s18_18.hip"]
-SOURCES = GEMM_PARTS + ["slice_gemm.hip", "slice_gemm_one_launch.hip", "topology.hip", "split.hip", "convert.hip", "api.cpp", "config.cpp", "kernel_policy.cpp", "interpose.cpp"]
-HEADERS = ["kernels.h", "config.h", "topology.h", "tile_plan.h", "kernel_policy.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", "slice_gemm_x_tile.h", "slice_gemm_y_tile.h", "slice_gemm_k2_kernel.h",
+SOURCES = GEMM_PARTS + ["slice_gemm.hip", "slice_gemm_one_launch.hip", "topology.hip", "split.hip", "convert.hip", "api.cpp", "config.cpp", "kernel_policy.cpp", "kernel_tuner.cpp", "interpose.cpp"]
+HEADERS = ["kernels.h", "config.h", "topology.h", "tile_plan.h", "kernel_policy.h", "kernel_tuner.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", "slice_gemm_x_tile.h", "slice_gemm_y_tile.h", "slice_gemm_k2_kernel.h",
            "slice_gemm_launch.h", "split_resident.h", "one_launch.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
 ARCH = "gfx950"
 

@@ -19,6 +19,7 @@
 #include "config.h"
 #include "handle.h"
 #include "kernel_policy.h"
+#include "kernel_tuner.h"
 #include "kernels.h"
 #include "layout.h"
 #include "one_launch.h"
@@ -474,6 +475,17 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   ba.tag = bb.tag = xw.tag;
 
   const bool prof = h->profiling && !stream_is_capturing(h->stream); // the stage timer synchronises on its events
+  // measured kernel choice for shapes the handle sees again (kernel_tuner.h): plain single-pass real GEMMs only
+  struct TunedCall {
+    TuneTicket tk;
+    bool ok = false;
+    ~TunedCall() { tuner_end(tk, ok); }
+  } tuned;
+  bool tune = bs.count == 1 && !dump && !prof && !have_row_max && k <= kc && S <= SINGLE_PASS_MAX_S && !stream_is_capturing(h->stream);
+#ifdef OZIMMU_HIP_TEST_HOOKS
+  tune = tune && config().test_fail_launch == 0;
+#endif
+  if (tune) tuned.tk = tuner_begin(h, h->device, S, m, n, k, (unsigned)k_blocks(k), h->stream);
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
   const bool use_phase = wants_phase(m, n, k, bs.count);
   // the phase hints / claim counters are cleared by the first row-maximum launch on the side (kernels.h: SplitJobs::zero_ptr);
@@ -533,6 +545,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
     if (e == hipSuccess) {
       h->last_kernel[0] = last_pick(0);
       h->last_kernel[1] = -1;
+      tuned.ok = true;
       return 0;
     }
     if (e != hipErrorNotSupported) {
@@ -594,6 +607,7 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
     }
     h->stage_calls++;
   }
+  tuned.ok = true;
   return 0;
 }
 
@@ -983,6 +997,17 @@ int ozimmu_hip_last_kernel(ozimmu_hip_handle_t h, int out[2]) {
   return 0;
 }
 
+int ozimmu_hip_tuner_state(ozimmu_hip_handle_t h, int num_split, size_t m, size_t n, size_t k, int out[2]) {
+  if (!h || !out) return -1;
+  std::lock_guard<std::recursive_mutex> lock(h->mtx);
+  int cur = h->device; // (collecting finished samples queries events of the handle's device)
+  const bool sw = hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess;
+  out[0] = out[1] = -1;
+  const int st = tuner_state(h, num_split, m, n, k, &out[0], &out[1]);
+  if (sw) hipSetDevice(cur);
+  return st;
+}
+
 int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
   if (h) {
     log_info("Destroying ozIMMU handle");
@@ -997,6 +1022,7 @@ int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
     for (auto &e : h->ev)
       if (e) hipEventDestroy(e);
     if (h->tail_ev) hipEventDestroy(h->tail_ev);
+    tuner_forget(h);
     delete h;
   }
   return 0;

@@ -80,6 +80,11 @@ void note_pick(int pass_index, int code) {
 }
 int last_pick(int pass_index) { return pass_index >= 0 && pass_index < 2 ? t_last_pick[pass_index] : -1; }
 
+// kernel_tuner.h: the prediction slot a tuned call of this thread runs (a candidate being timed, or the measured winner)
+static thread_local int t_override = -1;
+void policy_override(int slot);
+void policy_override(int slot) { t_override = slot; }
+
 Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topology &topo, const Config &cfg) {
   double p[POLICY_PARAMS];
   policy_params_get(p);
@@ -186,8 +191,10 @@ Prediction policy_predict(const PassTraits &t, const PolicyInput &in, const Topo
       else if (cfg.paired_tile == 1 && ok((int)Pick::WIDE_X16)) best = (int)Pick::WIDE_X16;
     }
   }
+  const bool tuned = !is_forced && t_override >= 0 && t_override < POLICY_KERNELS && ok(t_override);
+  if (tuned) best = t_override; // measured choice (kernel_tuner.cpp): every kernel returns the same bits
   // k64: B through LDS or in registers (OZIMMU_HIP_K64_BREG=0 keeps the register form out of `ok`, =1 takes it wherever it exists)
-  if ((best == K64 || best == K64R) && ok(K64R)) best = (cfg.k64_breg == 1 || r.us[K64R] <= r.us[K64]) ? K64R : K64;
+  if (!tuned && (best == K64 || best == K64R) && ok(K64R)) best = (cfg.k64_breg == 1 || r.us[K64R] <= r.us[K64]) ? K64R : K64;
   r.breg = best == 5;
   r.pick = best == 5 ? Pick::WIDE_K64 : (Pick)best;
   if (r.pick != Pick::CLASSIC) r.classic_wm4 = false;

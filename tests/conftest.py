@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # process: make the library follow the environment on every use (csrc/config.h; production reads them once per process).
 # Subprocess tests (LD_PRELOAD drivers) strip OZIMMU_* and run the production behaviour.
 os.environ.setdefault("OZIMMU_HIP_ENV_PER_CALL", "1")
+# The measured kernel choice (csrc/kernel_tuner.h) is OFF for the suite: one session-wide handle sees the same shapes again and
+# again, and the tests that assert WHICH kernel the cost model picks must not depend on what a timing decides.
+# tests/test_gpu_tuner.py switches it on for its own handles; the LD_PRELOAD subprocess tests run with it on (production).
+os.environ.setdefault("OZIMMU_HIP_AUTOTUNE", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
