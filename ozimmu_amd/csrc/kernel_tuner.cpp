@@ -2,6 +2,7 @@
 #include "kernel_tuner.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -31,6 +32,9 @@ constexpr double TUNE_MARGIN = 0.985; // another kernel replaces the model's pic
 constexpr float TUNE_MARGIN_MS = 0.001f; // ... minus a microsecond (calls of tens of microseconds: event granularity)
 constexpr unsigned TUNE_MAX_KB = 64;  // k loops of at most this many k-blocks (K <= 2048): where the model's misses are (its regret on
                                       // longer loops is < 0.5 %, and a sample there costs milliseconds)
+constexpr double TUNE_MIN_US = 100.0; // calls the model predicts shorter than this are not tuned: twelve of them end inside the clock ramp of
+                                      // a part that comes out of idle, and their times decided 1024^3 (29 us predicted) wrongly in one run
+                                      // of three (-5 %, for good: a decision is never revisited)
 constexpr size_t TUNE_MAX_SHAPES = 64; // per handle; further shapes run the model's pick
 constexpr size_t TUNE_MAX_PENDING = 24; // event pairs in flight per handle
 
@@ -68,12 +72,14 @@ std::mutex g_mtx;
 std::unordered_map<const void *, Tuner> g_tuners;
 
 bool enabled() {
-  static int once = -1;
-  if (config().env_per_call || once < 0) {
+  static std::atomic<int> once{-1}; // read once per process, like every OZIMMU_HIP_* switch (csrc/config.h); tests follow the environment
+  int v = once.load(std::memory_order_relaxed);
+  if (config().env_per_call || v < 0) {
     const char *e = std::getenv("OZIMMU_HIP_AUTOTUNE");
-    once = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
+    v = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
+    once.store(v, std::memory_order_relaxed);
   }
-  return once == 1;
+  return v == 1;
 }
 
 hipEvent_t take_event(Tuner &t) {
@@ -105,7 +111,10 @@ void decide(Entry &e) {
   float best_ms = base;
   for (int c = 1; c < e.ncand && base > 0.f; c++) {
     const float t = median_of(e.ms[c], e.samples[c]);
-    if (t > 0.f && t < best_ms && t < (float)TUNE_MARGIN * base - TUNE_MARGIN_MS) {
+    // ... and round by round (sample r of both comes from the same round: a drift of the clock over the exploration cancels)
+    int rounds_won = 0, rounds = std::min(e.samples[0], e.samples[c]);
+    for (int r = 0; r < rounds; r++) rounds_won += e.ms[c][r] < e.ms[0][r] ? 1 : 0;
+    if (t > 0.f && t < best_ms && t < (float)TUNE_MARGIN * base - TUNE_MARGIN_MS && 2 * rounds_won > rounds) {
       best = c;
       best_ms = t;
     }
@@ -183,6 +192,7 @@ TuneTicket tuner_begin(const void *owner, int device, int S, size_t m, size_t n,
       if (s == model || r.us[s] < 0 || r.us[model] <= 0 || r.us[s] > band * r.us[model]) continue;
       e.slot[e.ncand++] = s;
     }
+    if (r.us[model] < TUNE_MIN_US) e.ncand = 1;
     if (e.ncand == 1) {
       e.decided = true;
       e.winner = model;

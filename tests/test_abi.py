@@ -161,6 +161,11 @@ def test_null_handle_is_rejected_not_dereferenced(lib):
     assert lib.ozimmu_hip_destroy(None) == 0
     assert lib.ozimmu_hip_reallocate_working_memory(None, 1 << 20) == 0
     lib.ozimmu_hip_set_stream(None, None)
+    out = (ctypes.c_int * 2)()
+    lib.ozimmu_hip_tuner_state.restype = ctypes.c_int
+    lib.ozimmu_hip_tuner_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                                           ctypes.POINTER(ctypes.c_int)]
+    assert lib.ozimmu_hip_tuner_state(None, 9, 64, 64, 64, out) == -1  # (the measured kernel choice: no handle, no table)
 
 
 def test_product_has_no_cpu_fallback():

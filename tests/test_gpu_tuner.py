@@ -27,6 +27,8 @@ def _sync():
 def _candidates(m_, h, S, m, n, k):
     pred, pick = m_.policy_predict(h, S, m, n, k)
     base = pred[pick]
+    if base < 100.0:  # TUNE_MIN_US: short calls keep the model's pick
+        return [pick]
     band = 1.25 if (k + 31) // 32 <= 16 else 1.12  # csrc/kernel_tuner.cpp: TUNE_BAND_SHORT / TUNE_BAND
     others = sorted((v, nm) for nm, v in pred.items() if nm != pick and v <= band * base)
     return [pick] + [nm for _, nm in others][:2]
@@ -71,11 +73,11 @@ class _Case:
         np.testing.assert_array_equal(self.c.download().view(np.uint64), self.want)
 
 
-SHAPES = [(1536, 1280, 256), (2048, 2048, 256), (1024, 1024, 384), (2048, 1536, 512), (1280, 1024, 512), (4096, 4096, 256),
-          (3072, 2048, 128), (768, 768, 768), (1024, 1024, 1024)]
+# (calls the model predicts under 100 us are not tuned: outputs of >= 1e7 elements here)
+SHAPES = [(4096, 4096, 256), (3072, 4096, 384), (2048, 2048, 2048), (1536, 1536, 1536), (4096, 2048, 512), (4096, 4096, 384)]
 
 
-@pytest.mark.parametrize("S", [9, 6])
+@pytest.mark.parametrize("S", [9, 8])
 def test_exploration_is_bit_exact_visits_every_candidate_and_settles(oz, monkeypatch, S):
     m_, _ = oz
     monkeypatch.setenv("OZIMMU_HIP_AUTOTUNE", "1")
@@ -147,7 +149,7 @@ def test_one_candidate_is_decided_without_a_measurement(oz, monkeypatch):
     monkeypatch.delenv("OZIMMU_HIP_GEMM_KERNEL", raising=False)
     h = m_.create()
     try:
-        (m, n, k), cand = _shape_with(m_, h, 6, False, [(2048, 2048, 2048), (4096, 4096, 1024), (300, 300, 1500), (64, 64, 2048)])
+        (m, n, k), cand = _shape_with(m_, h, 6, False, [(300, 300, 1500), (2048, 2048, 2048), (4096, 4096, 1024), (64, 64, 2048)])
         case = _Case(m, n, k, 6, seed=11, beta=0.0)
         assert case.call(m_, h) == 0
         _sync()
