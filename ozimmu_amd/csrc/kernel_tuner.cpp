@@ -18,7 +18,8 @@ namespace ozhip {
 
 namespace {
 
-constexpr int TUNE_MAX_CAND = 3;      // candidates per shape
+constexpr int TUNE_MAX_CAND = 4;      // candidates per shape (8192^2 x 256: the model's order is classic, k64, wide, k64 in registers - and the
+                                      // last one is the fastest by 3 %)
 constexpr int TUNE_SAMPLES = 3;       // whole-call times per candidate that count; the median decides
 constexpr int TUNE_ROUNDS = TUNE_SAMPLES + 1; // rounds of one sample per candidate; round 0 is thrown away (a part that comes out of
                                       // idle ramps its clock over the first calls: whoever is timed later looks faster) and each
@@ -36,7 +37,7 @@ constexpr double TUNE_MIN_US = 100.0; // calls the model predicts shorter than t
                                       // a part that comes out of idle, and their times decided 1024^3 (29 us predicted) wrongly in one run
                                       // of three (-5 %, for good: a decision is never revisited)
 constexpr size_t TUNE_MAX_SHAPES = 64; // per handle; further shapes run the model's pick
-constexpr size_t TUNE_MAX_PENDING = 24; // event pairs in flight per handle
+constexpr size_t TUNE_MAX_PENDING = 32; // event pairs in flight per handle
 
 struct Key {
   int S;
@@ -47,8 +48,8 @@ struct Key {
 struct Entry {
   Key key{};
   int ncand = 0;
-  int slot[TUNE_MAX_CAND] = {-1, -1, -1};
-  int samples[TUNE_MAX_CAND] = {0, 0, 0};
+  int slot[TUNE_MAX_CAND] = {-1, -1, -1, -1};
+  int samples[TUNE_MAX_CAND] = {0, 0, 0, 0};
   int issued = 0;   // samples asked for so far (round = issued / ncand)
   int inflight = 0; // ... of which not collected yet
   float ms[TUNE_MAX_CAND][TUNE_SAMPLES] = {};

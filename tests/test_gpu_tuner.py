@@ -31,7 +31,7 @@ def _candidates(m_, h, S, m, n, k):
         return [pick]
     band = 1.25 if (k + 31) // 32 <= 16 else 1.12  # csrc/kernel_tuner.cpp: TUNE_BAND_SHORT / TUNE_BAND
     others = sorted((v, nm) for nm, v in pred.items() if nm != pick and v <= band * base)
-    return [pick] + [nm for _, nm in others][:2]
+    return [pick] + [nm for _, nm in others][:3]  # TUNE_MAX_CAND = 4
 
 
 def _shape_with(m_, h, S, want, shapes):

@@ -34,7 +34,7 @@ def asm(tmp_path_factory):
         # the library build (python -m ozimmu_amd.build, -save-temps=obj) leaves the device assembly behind: use it if
         # it is newer than every source, else compile
         kept = B.device_asm_path(src)
-        deps = headers + [os.path.join(CSRC, src)]
+        deps = sorted(B._closure(os.path.join(CSRC, src)))  # the source and the project headers it includes, like the build
         if os.path.exists(kept) and all(os.path.getmtime(kept) >= os.path.getmtime(f) for f in deps):
             return open(kept).read()
         o = d / (src + ".s")
