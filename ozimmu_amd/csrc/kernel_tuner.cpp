@@ -36,6 +36,9 @@ constexpr unsigned TUNE_MAX_KB = 64;  // k loops of at most this many k-blocks (
 constexpr double TUNE_MIN_US = 100.0; // calls the model predicts shorter than this are not tuned: twelve of them end inside the clock ramp of
                                       // a part that comes out of idle, and their times decided 1024^3 (29 us predicted) wrongly in one run
                                       // of three (-5 %, for good: a decision is never revisited)
+constexpr int TUNE_RECHECK_CALLS = 64; // a shape still in use this many calls after its first decision is measured once more, and that
+                                      // second measurement stands: the first sixteen calls of a part that is still warming up do not always
+                                      // rank kernels 3-5 % apart the way the steady state does (profiles/r5_policy/bench_regret_x2_r5k.txt)
 constexpr size_t TUNE_MAX_SHAPES = 64; // per handle; further shapes run the model's pick
 constexpr size_t TUNE_MAX_PENDING = 32; // event pairs in flight per handle
 
@@ -55,6 +58,8 @@ struct Entry {
   float ms[TUNE_MAX_CAND][TUNE_SAMPLES] = {};
   bool decided = false;
   int winner = -1; // prediction slot
+  int phase = 0;   // 0: first measurement, 1: second (final) one
+  int calls = 0;   // decided calls since the first decision
 };
 
 struct Pending {
@@ -202,13 +207,19 @@ TuneTicket tuner_begin(const void *owner, int device, int S, size_t m, size_t n,
     idx = (int)t.entries.size() - 1;
   }
   Entry &e = t.entries[(size_t)idx];
+  if (e.decided && e.phase == 0 && e.ncand > 1 && ++e.calls >= TUNE_RECHECK_CALLS) {
+    e.phase = 1; // (nothing of this entry is in flight: a decision needs every asked-for sample collected)
+    e.decided = false;
+    e.issued = 0;
+    for (int c = 0; c < e.ncand; c++) e.samples[c] = 0;
+  }
   if (e.decided) {
     policy_override(e.winner);
     return tk;
   }
   if (e.issued >= TUNE_ROUNDS * e.ncand || t.pending.size() >= TUNE_MAX_PENDING) {
-    policy_override(e.slot[0]); // everything asked for is in flight: the model's pick until the times are in
-    return tk;
+    policy_override(e.winner >= 0 ? e.winner : e.slot[0]); // everything asked for is in flight: the first decision (or the model's pick)
+    return tk;                                              // until the times are in
   }
   // round r times every candidate once, starting with candidate r (the first call of a shape runs the model's pick)
   const int round = e.issued / e.ncand, c = (e.issued % e.ncand + round) % e.ncand;

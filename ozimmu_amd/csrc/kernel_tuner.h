@@ -7,7 +7,8 @@
 // calls of a (mode, m, n, k) on a handle run the candidates the model predicts within 25 % (k loops of <= 16 k-blocks; 12 % beyond) of its best in turn (the
 // model's own pick first; four rounds, the first one thrown away), each whole call bracketed by two events on the caller's
 // stream; later calls of the shape collect the finished pairs WITHOUT waiting (hipEventQuery) and, once the rounds are in,
-// keep the kernel with the smallest median - the model's pick unless another beats it by TUNE_MARGIN and in most rounds.  No host synchronisation, no extra launch; a
+// keep the kernel with the smallest median - the model's pick unless another beats it by TUNE_MARGIN and in most rounds.
+// A shape still in use 64 calls later is measured once more (the part is warm by then) and that result stands.  No host synchronisation, no extra launch; a
 // shape seen once (HPL's shrinking trailing matrix) runs what the model picks, as before.  Not tuned: forced kernels and the
 // development switches, batches, ZGEMM products, K > 2048, calls predicted under 100 us, two-pass modes, captured streams, the stage timer, the test
 // hooks.  OZIMMU_HIP_AUTOTUNE=0 switches it off.  The reference has no counterpart (cuBLAS plans its own kernels,
