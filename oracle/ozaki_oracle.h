@@ -6,15 +6,15 @@
  * and there only as the checker.  The product (libozimmu_hip.so) never links,
  * loads or calls this code.
  *
- * PARITY STATUS: the reference (CUDA C++, needs nvcc + cuBLAS + the un-vendored
- * `cutf` headers) cannot be built in this image, and its tree holds no golden
- * vectors, known-answer tests or fixtures.  The only number the reference's own
- * tests pin on this path is the CI gate `relative_residual < 1e-15` for
- * fp64_int8_8..16 on uniform(0,1] inputs at m,n,k in {1023,1024,1025}, all four
- * op combinations (test/main_test.cu:702-746).  tests/test_oracle.py pins this
- * restatement against that gate; slice values / max_exp / INT32 products are
- * "parity unpinned" by the reference itself and are pinned here by exact
- * identities (reconstruction of the truncated mantissa, int64 matmul).
+ * PARITY STATUS: the reference's arithmetic units (src/split.cu, src/gemm.cu; CUDA C++ needing nvcc + cuBLAS + the
+ * un-vendored `cutf` headers) cannot be built in this image, and its tree holds no golden vectors, known-answer tests or
+ * fixtures: the floating-point / slice arithmetic restated here is PARITY UNPINNED by compiled reference code.
+ * What IS pinned against the reference compiled from its own source (oracle/_ref, src/config.cu built where it lies;
+ * tests/test_ref_pin.py): oz_oracle_num_split_from_mode, oz_oracle_pair_list (count AND order = the order of the FP64
+ * accumulation), oz_oracle_pad4 / the plane geometry.  The only number the reference's own tests pin on this path is the
+ * CI gate `relative_residual < 1e-15` for fp64_int8_8..16 on uniform(0,1] inputs at m,n,k in {1023,1024,1025}, all four
+ * op combinations (test/main_test.cu:702-746): tests/test_oracle.py holds this restatement to that gate; slice values /
+ * max_exp / INT32 products are pinned by exact identities (reconstruction of the truncated mantissa, int64 matmul).
  *
  * All matrices are column-major (BLAS convention), like the reference.
  * Every function cites the reference lines (relative to /root/reference) it
