@@ -119,12 +119,30 @@ int ozimmu_hip_policy_predict_device(int device, int num_split, int pass, size_t
                                      double out_us[6], int *pick);
 int ozimmu_hip_last_kernel(ozimmu_hip_handle_t handle, int out[2]);
 /* Measured kernel choice (csrc/kernel_tuner.h; no counterpart in the reference, whose GEMMs cuBLAS plans): a plain real GEMM
- * whose (mode, m, n, k) the handle has seen before runs, in turn, the kernels the model predicts within 25 % (K <= 512; 12 % up to K = 2048) of its best - all
- * of them return the same bits - each call bracketed by two events on the caller's stream, and keeps the fastest once four
- * rounds of times (the first one discarded) are in (no synchronisation: finished event pairs are collected by later calls).  OZIMMU_HIP_AUTOTUNE=0
- * switches it off.  ozimmu_hip_tuner_state: -1 = shape unknown to this handle, 0 = still measuring, 1 = decided;
- * out[0] = prediction slot (0..5, as in ozimmu_hip_policy_predict) of the decided kernel or -1, out[1] = candidates. */
+ * whose (mode, op_A, op_B, m, n, k, beta != 0) the handle is called with for the 8th time (OZIMMU_HIP_AUTOTUNE_AFTER) starts a
+ * measurement: the kernels the model predicts within 25 % (K <= 512; 12 % up to K = 2048) of its best - all of them return the
+ * same bits - run in turn, each call bracketed by two events on the caller's stream, and the fastest is kept once four rounds
+ * of times (the first one discarded) are in (no synchronisation: finished event pairs are collected by later calls); the shape
+ * is measured again 64, 512, 4096 ... calls later.  Calls 1 .. 7 of a shape run what the model picks, untimed.  Never on a
+ * handle that has been captured into a graph.  OZIMMU_HIP_AUTOTUNE=0 switches it off.
+ * ozimmu_hip_tuner_state: -1 = shape unknown to this handle, 0 = counting calls or measuring, 1 = decided;
+ * out[0] = prediction slot (0..5, as in ozimmu_hip_policy_predict) of the decided kernel or -1, out[1] = candidates; the most
+ * recently used entry of any layout / beta class.  _ex: exactly that class (op_A < 0: any), out[2] = calls seen, out[3] =
+ * measurements finished. */
 int ozimmu_hip_tuner_state(ozimmu_hip_handle_t handle, int num_split, size_t m, size_t n, size_t k, int out[2]);
+int ozimmu_hip_tuner_state_ex(ozimmu_hip_handle_t handle, int num_split, int op_A, int op_B, int beta_nonzero, size_t m, size_t n,
+                              size_t k, int out[4]);
+/* Measurement aid (bench.py: roofline.frac_of_measured_mfma_ceiling): the INT8 rate the matrix pipe of `device` (< 0: the
+ * current one) sustains on v_mfma_i32_16x16x64_i8 alone - random operands in registers, no memory traffic - over the last
+ * 60 % of `seconds` (<= 30) of back-to-back launches, in TOPS (2 ops per MAC).  Synchronises the device.  0 = ok. */
+int ozimmu_hip_mfma_ceiling(int device, double seconds, double *tops);
+/* Process-wide diagnostics of the LD_PRELOAD boundary (csrc/interpose.cpp; the reference only has its log lines,
+ * src/cublas.cu:153-166): out[0] = FP64 GEMM calls that reached an interposed entry point with a compute mode other than
+ * `dgemm`, out[1] = ... that ran on the Ozaki path, out[2] = ... left to the vendor routine (thresholds, pointer mode,
+ * status 3), out[3] = ... failed after C was modified (status 4); out[4 + c] = slice-GEMM launches (first diagonal pass)
+ * of kernel code c (the codes of ozimmu_hip_last_kernel: 0 k2, 1 classic, 2 wide, 3 x16, 4 k64, 12 k64 in registers,
+ * 16 k2 one launch), direct API calls included.  `count` entries are written (28 are defined). */
+int ozimmu_hip_intercept_stats(unsigned long long *out, int count);
 int ozimmu_hip_destroy(ozimmu_hip_handle_t handle);
 
 /* ozimmu.hpp:50-51 set_cuda_stream (src/handle.cu:54-61). `hip_stream` is a hipStream_t. */

@@ -234,16 +234,43 @@ def last_kernel(handle):
     return [KERNEL_NAMES.get(v[0], str(v[0])), KERNEL_NAMES.get(v[1], str(v[1]))]
 
 
-def tuner_state(handle, mode, m, n, k):
-    """measured kernel choice of this handle for a plain real GEMM shape: (state, slot, candidates); state -1 = unknown shape,
-    0 = still measuring, 1 = decided on prediction slot `slot` (index into KERNELS of policy_predict)"""
-    v = (C.c_int * 2)()
+def mfma_ceiling(seconds=2.0, device=-1):
+    """INT8 TOPS the matrix pipe sustains on v_mfma_i32_16x16x64_i8 alone (random operands, no memory traffic), steady state"""
     L = lib()
-    L.ozimmu_hip_tuner_state.restype = C.c_int
-    L.ozimmu_hip_tuner_state.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    L.ozimmu_hip_mfma_ceiling.restype = C.c_int
+    L.ozimmu_hip_mfma_ceiling.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_double)]
+    v = C.c_double(0.0)
+    if L.ozimmu_hip_mfma_ceiling(device, float(seconds), C.byref(v)) != 0:
+        raise RuntimeError("ozimmu_hip_mfma_ceiling failed")
+    return v.value
+
+
+def intercept_stats():
+    """process-wide counters of the LD_PRELOAD boundary + the kernel histogram (include/ozimmu_hip.h: ozimmu_hip_intercept_stats)"""
+    L = lib()
+    out = (C.c_ulonglong * 28)()
+    L.ozimmu_hip_intercept_stats.restype = C.c_int
+    L.ozimmu_hip_intercept_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    L.ozimmu_hip_intercept_stats(out, 28)
+    v = list(out)
+    return {"seen": v[0], "taken": v[1], "declined": v[2], "failed": v[3],
+            "kernels": {KERNEL_NAMES.get(c, str(c)): v[4 + c] for c in range(24) if v[4 + c]}}
+
+
+def tuner_state(handle, mode, m, n, k, op_a=None, op_b=None, beta_nonzero=False, full=False):
+    """measured kernel choice of this handle for a plain real GEMM shape: (state, slot, candidates); state -1 = unknown shape,
+    0 = counting calls or measuring, 1 = decided on prediction slot `slot` (index into KERNELS of policy_predict).  Without
+    op_a / op_b: the most recently used entry of any layout / beta class.  full=True: + (calls seen, measurements finished)"""
+    v = (C.c_int * 4)()
+    L = lib()
+    L.ozimmu_hip_tuner_state_ex.restype = C.c_int
+    L.ozimmu_hip_tuner_state_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.POINTER(C.c_int)]
     S = int(str(mode).rsplit("_", 1)[1])
-    st = L.ozimmu_hip_tuner_state(handle.ptr, S, m, n, k, v)
-    return st, v[0], v[1]
+    oa = -1 if op_a is None else _op(op_a)
+    ob = -1 if op_b is None else _op(op_b)
+    st = L.ozimmu_hip_tuner_state_ex(handle.ptr, S, oa, ob, 1 if beta_nonzero else 0, m, n, k, v)
+    return (st, v[0], v[1], v[2], v[3]) if full else (st, v[0], v[1])
 
 
 def set_auto_mantissa_loss_threashold(handle, threshold):

@@ -11,6 +11,7 @@
 The .so is git-ignored but travels with the tree (gpurun snapshot); nothing is installed or JIT-cached.
 """
 import concurrent.futures
+import hashlib
 import os
 import re
 import shutil
@@ -24,7 +25,7 @@ LIB_TEST = os.path.join(HERE, "libozimmu_hip_test.so")
 GEMM_PARTS = ["slice_gemm_s3_4.hip", "slice_gemm_s5_6.hip", "slice_gemm_s7_7.hip", "slice_gemm_s8_8.hip", "slice_gemm_s9_9.hip", "slice_gemm_s10_10.hip", "slice_gemm_s11_11.hip", "slice_gemm_s12_12.hip", "slice_gemm_s13_13.hip", "slice_gemm_s14_14.hip", "slice_gemm_s15_15.hip", "slice_gemm_s16_16.hip", "slice_gemm_s17_17.hip", "slice_gemm_s18_18.hip"]
 SOURCES = GEMM_PARTS + ["slice_gemm.hip", "slice_gemm_one_launch.hip", "topology.hip", "split.hip", "convert.hip", "api.cpp", "config.cpp", "kernel_policy.cpp", "kernel_tuner.cpp", "interpose.cpp"]
 HEADERS = ["kernels.h", "config.h", "topology.h", "tile_plan.h", "kernel_policy.h", "kernel_tuner.h", "layout.h", "handle.h", "slice_gemm_kernel.h", "slice_gemm_w_kernel.h", "slice_gemm_x_tile.h", "slice_gemm_y_tile.h", "slice_gemm_k2_kernel.h",
-           "slice_gemm_launch.h", "split_resident.h", "one_launch.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
+           "slice_gemm_launch.h", "split_resident.h", "one_launch.h", "diagnostics.h", os.path.join("..", "..", "include", "ozimmu_hip.h")]
 ARCH = "gfx950"
 
 
@@ -91,11 +92,32 @@ def _flavour(hooks):
     return bdir, common, objs, (LIB_TEST if hooks else LIB)
 
 
+def _stamp_path(lib):
+    return lib + ".flags"
+
+
+def _flags_stamp(common):
+    """what a library was compiled with, besides its sources: the flag list (include path made relative), the architecture and
+    the source list.  Stored next to the library (it travels to the GPU box with it); a library whose stamp differs is stale
+    even when it is newer than every source (after a change of the flags or of ARCH a stale .so was reused silently
+    unless --force was passed - and the GPU box never has objects to notice by)."""
+    flags = [f.replace(CSRC, "csrc") for f in common]
+    return hashlib.sha256("\n".join(flags + [ARCH] + SOURCES).encode()).hexdigest()
+
+
+def _stamp_stale(lib, common):
+    try:
+        with open(_stamp_path(lib)) as f:
+            return f.read().strip() != _flags_stamp(common)
+    except OSError:
+        return False  # a library from before the stamps: taken as built with these flags, stamped by this run
+
+
 def build(force=False, verbose=False, test_flavour=True, product=True):
     """compiles the stale translation units of both flavours side by side (the slice-GEMM parts take minutes each), links
     libozimmu_hip.so (the product) and libozimmu_hip_test.so (with the test hooks); returns the product's path"""
     hipcc = _hipcc()
-    deps = [os.path.join(CSRC, h) for h in HEADERS]  # (compiler flags live in this file: after changing them, --force)
+    deps = [os.path.join(CSRC, h) for h in HEADERS]  # (compiler flags and ARCH: the stamp file next to each library)
     flavours = [_flavour(h) for h in ([False] if product else []) + ([True] if test_flavour else [])]
     jobs = []
     all_src = [os.path.join(CSRC, s) for s in SOURCES] + deps
@@ -105,20 +127,29 @@ def build(force=False, verbose=False, test_flavour=True, product=True):
     def _objects_stale(bdir, objs):
         return os.path.isdir(os.path.join(HERE, bdir)) and any(
             _stale(obj, sorted(_closure(os.path.join(CSRC, s)))) for s, obj in zip(SOURCES, objs))
-    flavours = [f for f in flavours if force or _stale(f[3], all_src) or _objects_stale(f[0], f[2])]
-    for bdir, common, objs, _ in flavours:
+    restamp = {f[3] for f in flavours if _stamp_stale(f[3], f[1])}  # other flags / architecture: everything of that flavour again
+    flavours = [f for f in flavours if force or f[3] in restamp or _stale(f[3], all_src) or _objects_stale(f[0], f[2])]
+    for bdir, common, objs, lib in flavours:
         os.makedirs(os.path.join(HERE, bdir), exist_ok=True)
-        jobs += [(common, s, bdir) for s, obj in zip(SOURCES, objs) if force or _stale(obj, sorted(_closure(os.path.join(CSRC, s))))]
+        jobs += [(common, s, bdir) for s, obj in zip(SOURCES, objs)
+                 if force or lib in restamp or _stale(obj, sorted(_closure(os.path.join(CSRC, s))))]
     jobs.sort(key=lambda j: j[1] not in GEMM_PARTS)  # the long ones first
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
         for f in [pool.submit(_compile, hipcc, common, s, verbose, bdir) for common, s, bdir in jobs]:
             f.result()
     for bdir, common, objs, lib in flavours:
-        if force or _stale(lib, objs):
+        if force or lib in restamp or _stale(lib, objs):
             cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + ["-ldl", "-lpthread"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            with open(_stamp_path(lib), "w") as f:
+                f.write(_flags_stamp(common) + "\n")
+    for hooks in ([False] if product else []) + ([True] if test_flavour else []):
+        _, common, _, lib = _flavour(hooks)
+        if os.path.exists(lib) and not os.path.exists(_stamp_path(lib)):
+            with open(_stamp_path(lib), "w") as f:
+                f.write(_flags_stamp(common) + "\n")
     return LIB
 
 

@@ -12,6 +12,7 @@
 #include <rocblas/rocblas.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <string>
@@ -352,6 +353,28 @@ static bool wants_phase(size_t m, size_t n, size_t k, size_t batch) {
   return (m * n >= (size_t)2560 * 1024 && k >= 1024) || config().wide_grid > 0;
 }
 
+// WorkspaceUse below: hand the blocks a capture has used over to the graph(s) - nothing is freed, the handle forgets them
+static bool leave_blocks_to_graphs(ozimmu_hip_handle_t h) {
+  const size_t bytes = h->current_working_memory_size + h->exp_words_bytes;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if (h->capture_retirements >= 8 || h->capture_retired_bytes + bytes > total_b / 8 || free_b < 2 * bytes) return false;
+  if (h->working_memory_ptr) h->retired_blocks.push_back(h->working_memory_ptr);
+  if (h->exp_words) h->retired_blocks.push_back(h->exp_words);
+  h->working_memory_ptr = nullptr;
+  h->current_working_memory_size = 0;
+  h->exp_words = nullptr;
+  h->exp_words_bytes = 0;
+  h->exp_epoch = 0;
+  h->exp_reuse.valid = false;
+  h->capture_retirements++;
+  h->capture_retired_bytes += bytes;
+  return true;
+}
+
 // Scope of one use of the handle's workspace on h->stream (construct before ensure_workspace, under h->mtx).
 // Calls on one stream are ordered by the stream.  As long as a handle has only ever seen ONE stream (the common case: a
 // BLAS handle bound to a stream, PyTorch's current stream) nothing else is done: an event recorded after every call
@@ -390,16 +413,30 @@ struct WorkspaceUse {
     const bool other_stream = h->tail_stream_known && h->tail_stream != h->stream && !config().test_no_stream_order;
     if (capturing) {
       ok = !other_stream;
+      if (ok) h->capture_dirty = true; // the graph being captured will point into the current blocks
       return;
     }
-    if (h->seen_capture && h->several_streams) {
+    bool synced = false;
+    if (h->seen_capture && h->several_streams && h->capture_dirty) {
       // A graph captured from this handle replays without the library seeing it: a replay records no tail event, and it may
-      // run on any stream.  Once a handle has been captured AND has seen more than one stream (capture streams included),
-      // the only ordering an eager call can get against a replay in flight is a device synchronisation (an
-      // application that keeps its graph replays and its eager GEMMs on ONE stream never gets here).
-      hipDeviceSynchronize();
-      (void)hipGetLastError();
-      h->multi_stream = true;
+      // run on any stream.  Once a handle has been captured AND has seen more than one stream (capture streams included), an
+      // eager call has no way to order itself against a replay in flight - so it does not share memory with one: the first
+      // eager call after a capture leaves the workspace and the exponent words the capture used to the graph (kept until the
+      // handle is destroyed, like every block a graph may point into) and runs, as every later eager call, on fresh blocks.
+      // No synchronisation.  (Rounds 3-5 synchronised the DEVICE in front of every eager call from then on, for ever: ADVICE
+      // r4)  What a pathological caller - capture, eager, capture, eager ... - can pin this way is bounded
+      // (8 hand-overs, an eighth of the device's memory); beyond that the old behaviour: a device synchronisation per call.
+      // (An application that keeps its graph replays and its eager GEMMs on ONE stream never gets here.)
+      if (leave_blocks_to_graphs(h)) {
+        h->capture_dirty = false;
+      } else {
+        hipDeviceSynchronize();
+        (void)hipGetLastError();
+        h->multi_stream = true;
+        synced = true;
+      }
+    }
+    if (synced) {
     } else if (other_stream) {
       if (h->multi_stream && h->tail_valid) {
         hipStreamWaitEvent(h->stream, h->tail_ev, 0);
@@ -479,13 +516,28 @@ static int gemm_int8_real(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu
   struct TunedCall {
     TuneTicket tk;
     bool ok = false;
-    ~TunedCall() { tuner_end(tk, ok); }
+    Tuner *t = nullptr;
+    ~TunedCall() { tuner_end(t, tk, ok); }
   } tuned;
-  bool tune = bs.count == 1 && !dump && !prof && !have_row_max && k <= kc && S <= SINGLE_PASS_MAX_S && !stream_is_capturing(h->stream);
+  // (never on a handle that has been captured into a graph: the tuner's hipEventQuery / hipEventRecord next to a capture that
+  // may be in flight on another thread are not worth finding out about - ADVICE r5)
+  bool tune = bs.count == 1 && !dump && !prof && !have_row_max && k <= kc && S <= SINGLE_PASS_MAX_S && !h->seen_capture &&
+              !stream_is_capturing(h->stream);
 #ifdef OZIMMU_HIP_TEST_HOOKS
   tune = tune && config().test_fail_launch == 0;
 #endif
-  if (tune) tuned.tk = tuner_begin(h, h->device, S, m, n, k, (unsigned)k_blocks(k), h->stream);
+  if (tune) {
+    TuneShape shape;
+    shape.S = S;
+    shape.op_a = (int)op_A;
+    shape.op_b = (int)op_B;
+    shape.beta_nonzero = beta != 0.0;
+    shape.m = m;
+    shape.n = n;
+    shape.k = k;
+    tuned.tk = tuner_begin(h->tuner, h->device, shape, (unsigned)k_blocks(k), h->stream);
+    tuned.t = h->tuner;
+  }
   if (prof && !hip_ok(hipEventRecord(h->ev[0], h->stream), "event")) return 3;
   const bool use_phase = wants_phase(m, n, k, bs.count);
   // the phase hints / claim counters are cleared by the first row-maximum launch on the side (kernels.h: SplitJobs::zero_ptr);
@@ -997,14 +1049,24 @@ int ozimmu_hip_last_kernel(ozimmu_hip_handle_t h, int out[2]) {
   return 0;
 }
 
-int ozimmu_hip_tuner_state(ozimmu_hip_handle_t h, int num_split, size_t m, size_t n, size_t k, int out[2]) {
+int ozimmu_hip_tuner_state_ex(ozimmu_hip_handle_t h, int num_split, int op_A, int op_B, int beta_nonzero, size_t m, size_t n,
+                              size_t k, int out[4]) {
   if (!h || !out) return -1;
   std::lock_guard<std::recursive_mutex> lock(h->mtx);
   int cur = h->device; // (collecting finished samples queries events of the handle's device)
   const bool sw = hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess;
-  out[0] = out[1] = -1;
-  const int st = tuner_state(h, num_split, m, n, k, &out[0], &out[1]);
+  out[0] = out[1] = out[2] = out[3] = -1;
+  const int st = tuner_state(h->tuner, num_split, op_A, op_B, beta_nonzero, m, n, k, out);
   if (sw) hipSetDevice(cur);
+  return st;
+}
+
+int ozimmu_hip_tuner_state(ozimmu_hip_handle_t h, int num_split, size_t m, size_t n, size_t k, int out[2]) {
+  if (!h || !out) return -1;
+  int v[4];
+  const int st = ozimmu_hip_tuner_state_ex(h, num_split, -1, -1, 0, m, n, k, v);
+  out[0] = v[0];
+  out[1] = v[1];
   return st;
 }
 
@@ -1022,7 +1084,7 @@ int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
     for (auto &e : h->ev)
       if (e) hipEventDestroy(e);
     if (h->tail_ev) hipEventDestroy(h->tail_ev);
-    tuner_forget(h);
+    tuner_forget(h->tuner);
     delete h;
   }
   return 0;
@@ -1350,7 +1412,20 @@ int ozimmu_hip_gemm(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, ozimmu_opera
     {
       // the statistic is read back on the host (blocking copy): impossible while the stream is captured into a graph
       std::lock_guard<std::recursive_mutex> lock(h->mtx);
-      if (stream_is_capturing(h->stream)) return 3;
+      if (stream_is_capturing(h->stream)) {
+        // The interposer captures the VENDOR routine for this call: the eager and the replayed runs of one program then
+        // differ in numerics.  Said once per process even without OZIMMU_INFO (OZIMMU_ERROR=0 silences it), every time with it.
+        static std::atomic<bool> said{false};
+        const char *msg = "AUTO: the call is being captured into a graph (the mantissa-loss statistic needs a host read-back): "
+                          "left to the vendor GEMM; select a fixed fp64_int8_N mode to capture the Ozaki path";
+        if (env_enabled("OZIMMU_INFO", false))
+          log_info(msg);
+        else if (!said.exchange(true) && env_enabled("OZIMMU_ERROR", true)) {
+          std::fprintf(stdout, "[ozIMMU LOG] %s\n", msg);
+          std::fflush(stdout);
+        }
+        return 3;
+      }
     }
     // statistic and GEMM under one lock: the GEMM may take over the row maxima the statistic pass has just computed
     std::lock_guard<std::recursive_mutex> lock(h->mtx);

@@ -14,6 +14,10 @@
 #include "../../include/ozimmu_hip.h"
 #include "config.h"
 
+namespace ozhip {
+struct Tuner;
+}
+
 struct ozimmu_hip_handle {
   hipStream_t stream = nullptr;
   int device = 0; // the device this handle was created on: workspace, topology and every launch belong to it
@@ -49,6 +53,12 @@ struct ozimmu_hip_handle {
   // freed, so that a replay never touches released memory.
   bool seen_capture = false;
   std::vector<void *> retired_blocks;
+  // A graph replays without the library seeing it.  On a handle that has seen more than one stream, the first EAGER call
+  // after a capture therefore leaves the blocks the capture used (workspace, exponent words) to the graph for good and
+  // continues on fresh ones: replays and eager calls never share memory, so they need no ordering (api.cpp: WorkspaceUse).
+  bool capture_dirty = false;      // a captured call has used the current blocks
+  int capture_retirements = 0;     // how often that happened ...
+  size_t capture_retired_bytes = 0; // ... and what it keeps allocated until the handle is destroyed (bounded: api.cpp)
   double avg_mantissa_loss_threshold = 0; // src/handle.hpp:26
 
   // src/handle.hpp:28-30, read at creation (src/handle.cu:25-30)
@@ -77,6 +87,9 @@ struct ozimmu_hip_handle {
   // diagnostics: the kernel (kernel_policy.h: Pick, + 8 = k64 with B in registers) the last slice-GEMM launch of this handle
   // ran for its first / second diagonal pass (-1: none)
   int last_kernel[2] = {-1, -1};
+
+  // measured kernel choice for the shapes this handle keeps calling (kernel_tuner.h); touched under mtx only
+  ozhip::Tuner *tuner = nullptr;
 
   // private vendor BLAS handle for the `dgemm` mode (src/handle.hpp:8), created lazily
   void *rocblas_handle = nullptr;

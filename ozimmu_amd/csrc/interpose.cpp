@@ -42,6 +42,7 @@
 #include <string>
 
 #include "config.h"
+#include "diagnostics.h"
 #include "handle.h"
 
 using namespace ozhip;
@@ -53,6 +54,9 @@ std::mutex g_mtx;
 // process that drives several GPUs would hand device-0 memory to device-1 kernels.  One handle per device here.
 std::map<int, ozimmu_hip_handle_t> g_handles;
 std::atomic<int> g_live_vendor_handles{0};
+// ozimmu_hip_intercept_stats: FP64 GEMM calls that reached an interposed entry point with a compute mode other than `dgemm`
+// / that ran on the Ozaki path / that were left to the vendor routine (predicate, thresholds, status 3) / that failed (status 4)
+std::atomic<unsigned long long> g_stat_seen{0}, g_stat_taken{0}, g_stat_declined{0}, g_stat_failed{0};
 thread_local int t_depth = 0;
 
 struct DepthGuard {
@@ -249,6 +253,8 @@ typename V::status entry(bool eligible, typename V::handle handle, typename V::o
       g.op_a = V::to_oz(ta);
       g.op_b = V::to_oz(tb);
       const Try t = try_ozaki(stream, host_mode, g, mode);
+      g_stat_seen.fetch_add(1, std::memory_order_relaxed);
+      (t == Try::Done ? g_stat_taken : t == Try::Failed ? g_stat_failed : g_stat_declined).fetch_add(1, std::memory_order_relaxed);
       if (t == Try::Done) return V::ok;
       if (t == Try::Failed) return V::err;
     }
@@ -305,6 +311,18 @@ void on_vendor_handle_destroyed() {
 } // namespace
 
 extern "C" {
+
+int ozimmu_hip_intercept_stats(unsigned long long *out, int count) {
+  if (!out || count < 0) return 1;
+  unsigned long long v[4 + ozhip::PICK_HIST_SLOTS];
+  v[0] = g_stat_seen.load(std::memory_order_relaxed);
+  v[1] = g_stat_taken.load(std::memory_order_relaxed);
+  v[2] = g_stat_declined.load(std::memory_order_relaxed);
+  v[3] = g_stat_failed.load(std::memory_order_relaxed);
+  ozhip::pick_histogram(v + 4);
+  for (int i = 0; i < count; i++) out[i] = i < 4 + ozhip::PICK_HIST_SLOTS ? v[i] : 0ull;
+  return 0;
+}
 
 // ---- lifecycle (src/cublas.cu:104-131) -----------------------------------------------------------------
 

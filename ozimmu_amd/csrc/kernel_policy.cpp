@@ -1,7 +1,10 @@
 // kernel_policy.cpp — the cost model behind the slice-GEMM kernel choice (kernel_policy.h).
 #include "kernel_policy.h"
 
+#include "diagnostics.h"
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <mutex>
 
@@ -75,8 +78,13 @@ void policy_params_set(const double *in, int count) {
 }
 
 static thread_local int t_last_pick[2] = {-1, -1};
+static std::atomic<unsigned long long> g_pick_hist[PICK_HIST_SLOTS];
 void note_pick(int pass_index, int code) {
   if (pass_index >= 0 && pass_index < 2) t_last_pick[pass_index] = code;
+  if (pass_index == 0 && code >= 0 && code < PICK_HIST_SLOTS) g_pick_hist[code].fetch_add(1, std::memory_order_relaxed);
+}
+void pick_histogram(unsigned long long out[PICK_HIST_SLOTS]) {
+  for (int i = 0; i < PICK_HIST_SLOTS; i++) out[i] = g_pick_hist[i].load(std::memory_order_relaxed);
 }
 int last_pick(int pass_index) { return pass_index >= 0 && pass_index < 2 ? t_last_pick[pass_index] : -1; }
 

@@ -3,10 +3,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
-#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -35,17 +35,32 @@ constexpr unsigned TUNE_MAX_KB = 64;  // k loops of at most this many k-blocks (
                                       // longer loops is < 0.5 %, and a sample there costs milliseconds)
 constexpr double TUNE_MIN_US = 100.0; // calls the model predicts shorter than this are not tuned: twelve of them end inside the clock ramp of
                                       // a part that comes out of idle, and their times decided 1024^3 (29 us predicted) wrongly in one run
-                                      // of three (-5 %, for good: a decision is never revisited)
-constexpr int TUNE_RECHECK_CALLS = 64; // a shape still in use this many calls after its first decision is measured once more, and that
-                                      // second measurement stands: the first sixteen calls of a part that is still warming up do not always
-                                      // rank kernels 3-5 % apart the way the steady state does (profiles/r5_policy/bench_regret_x2_r5k.txt)
-constexpr size_t TUNE_MAX_SHAPES = 64; // per handle; further shapes run the model's pick
+                                      // of three (-5 %)
+constexpr int TUNE_FIRST_CALL = 8;    // the first measured call of a shape (a shape seen 2-15 times ran candidates
+                                      // predicted up to 25 % slower on calls 2, 3, 4 ... and never reached the decision that pays for them)
+constexpr int TUNE_RECHECK_CALLS = 64; // a shape still in use this many calls after a decision is measured again: the first sixteen calls
+                                      // of a part that is still warming up do not always rank kernels 3-5 % apart the way the steady
+                                      // state does (profiles/r5_policy/bench_regret_x2_r5k.txt) ...
+constexpr int TUNE_RECHECK_GROWTH = 8; // ... and then 512, 4096, ... calls later: whatever shared the device with the sampled calls
+                                      // (another stream's kernels) is in the samples, so no measurement is final; a measurement is
+                                      // <= 16 calls of which the non-winners run up to 25 % slower: < 0.1 % of the calls between two looks
+constexpr size_t TUNE_MAX_SHAPES = 256; // per handle; the least recently used shape without a sample in flight makes room
 constexpr size_t TUNE_MAX_PENDING = 32; // event pairs in flight per handle
 
 struct Key {
-  int S;
-  size_t m, n, k;
-  bool operator==(const Key &o) const { return S == o.S && m == o.m && n == o.n && k == o.k; }
+  int S = 0, op_a = 0, op_b = 0, beta_nz = 0;
+  size_t m = 0, n = 0, k = 0;
+  bool operator==(const Key &o) const {
+    return S == o.S && op_a == o.op_a && op_b == o.op_b && beta_nz == o.beta_nz && m == o.m && n == o.n && k == o.k;
+  }
+};
+struct KeyHash {
+  size_t operator()(const Key &x) const {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t v : {(uint64_t)x.S, (uint64_t)x.op_a, (uint64_t)x.op_b, (uint64_t)x.beta_nz, (uint64_t)x.m, (uint64_t)x.n, (uint64_t)x.k})
+      h = (h ^ v) * 1099511628211ull;
+    return (size_t)h;
+  }
 };
 
 struct Entry {
@@ -53,13 +68,16 @@ struct Entry {
   int ncand = 0;
   int slot[TUNE_MAX_CAND] = {-1, -1, -1, -1};
   int samples[TUNE_MAX_CAND] = {0, 0, 0, 0};
-  int issued = 0;   // samples asked for so far (round = issued / ncand)
+  int issued = 0;   // samples asked for so far in this measurement (round = issued / ncand)
   int inflight = 0; // ... of which not collected yet
   float ms[TUNE_MAX_CAND][TUNE_SAMPLES] = {};
   bool decided = false;
-  int winner = -1; // prediction slot
-  int phase = 0;   // 0: first measurement, 1: second (final) one
-  int calls = 0;   // decided calls since the first decision
+  int winner = -1;     // prediction slot
+  int measurements = 0; // finished ones
+  int seen = 0;        // calls of this shape so far (saturating)
+  long long calls = 0; // decided calls since the last decision
+  long long recheck_after = TUNE_RECHECK_CALLS;
+  unsigned long long last_use = 0;
 };
 
 struct Pending {
@@ -68,38 +86,49 @@ struct Pending {
   hipEvent_t start, stop;
 };
 
+} // namespace
+
 struct Tuner {
   std::vector<Entry> entries;
+  std::unordered_map<Key, int, KeyHash> index;
   std::deque<Pending> pending;
   std::vector<hipEvent_t> pool;
+  unsigned long long tick = 0;
 };
 
-std::mutex g_mtx;
-std::unordered_map<const void *, Tuner> g_tuners;
+namespace {
 
-bool enabled() {
-  static std::atomic<int> once{-1}; // read once per process, like every OZIMMU_HIP_* switch (csrc/config.h); tests follow the environment
+struct Switches {
+  bool on;
+  int first_call;
+};
+Switches switches() {
+  // read once per process, like every OZIMMU_HIP_* switch (csrc/config.h); tests follow the environment
+  static std::atomic<int> once{-1}, first{TUNE_FIRST_CALL};
   int v = once.load(std::memory_order_relaxed);
   if (config().env_per_call || v < 0) {
     const char *e = std::getenv("OZIMMU_HIP_AUTOTUNE");
     v = (e && e[0] == '0' && e[1] == 0) ? 0 : 1;
+    const char *a = std::getenv("OZIMMU_HIP_AUTOTUNE_AFTER");
+    first.store(a ? std::max(1, std::atoi(a)) : TUNE_FIRST_CALL, std::memory_order_relaxed);
     once.store(v, std::memory_order_relaxed);
   }
-  return v == 1;
+  return Switches{v == 1, first.load(std::memory_order_relaxed)};
 }
 
-hipEvent_t take_event(Tuner &t) {
-  if (!t.pool.empty()) {
-    hipEvent_t e = t.pool.back();
-    t.pool.pop_back();
-    return e;
+// all the events a handle's samples can have in flight, created in one go when its first measurement starts (never per call)
+bool fill_pool(Tuner &t) {
+  if (!t.pool.empty() || !t.pending.empty()) return true;
+  t.pool.reserve(2 * TUNE_MAX_PENDING);
+  for (size_t i = 0; i < 2 * TUNE_MAX_PENDING; i++) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+      (void)hipGetLastError();
+      break;
+    }
+    t.pool.push_back(e);
   }
-  hipEvent_t e = nullptr;
-  if (hipEventCreate(&e) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  return e;
+  return t.pool.size() >= 2;
 }
 
 float median_of(const float *v, int count) {
@@ -117,7 +146,8 @@ void decide(Entry &e) {
   float best_ms = base;
   for (int c = 1; c < e.ncand && base > 0.f; c++) {
     const float t = median_of(e.ms[c], e.samples[c]);
-    // ... and round by round (sample r of both comes from the same round: a drift of the clock over the exploration cancels)
+    // ... and round by round (sample r of both comes from the same round: a drift of the clock over the exploration cancels,
+    // and so does a neighbour on another stream that ran through one round and not the next)
     int rounds_won = 0, rounds = std::min(e.samples[0], e.samples[c]);
     for (int r = 0; r < rounds; r++) rounds_won += e.ms[c][r] < e.ms[0][r] ? 1 : 0;
     if (t > 0.f && t < best_ms && t < (float)TUNE_MARGIN * base - TUNE_MARGIN_MS && 2 * rounds_won > rounds) {
@@ -125,8 +155,11 @@ void decide(Entry &e) {
       best_ms = t;
     }
   }
-  e.winner = e.slot[best];
+  // a measurement that lost the model's own samples (failed calls, a destroyed stream) keeps what was decided before
+  if (base > 0.f || e.winner < 0) e.winner = e.slot[best];
   e.decided = true;
+  e.calls = 0;
+  if (e.measurements++ > 0) e.recheck_after *= TUNE_RECHECK_GROWTH;
 }
 
 // finished event pairs -> samples, oldest first (one stream: they finish in order; a pair that is not ready ends the sweep)
@@ -154,36 +187,51 @@ void collect(Tuner &t) {
   }
 }
 
+// the slot of a new shape: a free one, or the least recently used entry that has no sample in flight
+int make_room(Tuner &t) {
+  if (t.entries.size() < TUNE_MAX_SHAPES) {
+    t.entries.emplace_back();
+    return (int)t.entries.size() - 1;
+  }
+  int victim = -1;
+  for (size_t i = 0; i < t.entries.size(); i++)
+    if (t.entries[i].inflight == 0 && (victim < 0 || t.entries[i].last_use < t.entries[(size_t)victim].last_use)) victim = (int)i;
+  if (victim >= 0) {
+    t.index.erase(t.entries[(size_t)victim].key);
+    t.entries[(size_t)victim] = Entry();
+  }
+  return victim;
+}
+
 } // namespace
 
-TuneTicket tuner_begin(const void *owner, int device, int S, size_t m, size_t n, size_t k, unsigned nkb, hipStream_t stream) {
+TuneTicket tuner_begin(Tuner *&tp, int device, const TuneShape &shape, unsigned nkb, hipStream_t stream) {
   TuneTicket tk;
   policy_override(-1);
   const Config cfg = config();
-  if (!enabled() || nkb > TUNE_MAX_KB || cfg.forced_kernel() || cfg.paired_tile >= 0 || cfg.k64_tile >= 0 || cfg.k64_breg >= 0 || cfg.wide_grid > 0 ||
+  const Switches sw = switches();
+  if (!sw.on || nkb > TUNE_MAX_KB || cfg.forced_kernel() || cfg.paired_tile >= 0 || cfg.k64_tile >= 0 || cfg.k64_breg >= 0 || cfg.wide_grid > 0 ||
       cfg.wide_static || cfg.wide_small_rows >= 0 || cfg.xcds > 0)
     return tk;
-  std::lock_guard<std::mutex> lock(g_mtx);
-  Tuner &t = g_tuners[owner];
+  if (!tp) tp = new Tuner();
+  Tuner &t = *tp;
   collect(t);
-  const Key key{S, m, n, k};
+  const Key key{shape.S, shape.op_a, shape.op_b, shape.beta_nonzero ? 1 : 0, shape.m, shape.n, shape.k};
   int idx = -1;
-  for (size_t i = 0; i < t.entries.size(); i++)
-    if (t.entries[i].key == key) {
-      idx = (int)i;
-      break;
-    }
+  auto it = t.index.find(key);
+  if (it != t.index.end()) idx = it->second;
   if (idx < 0) {
-    if (t.entries.size() >= TUNE_MAX_SHAPES) return tk;
     PassTraits tr;
-    if (!slice_gemm_traits(S, 0, &tr)) return tk;
+    if (!slice_gemm_traits(shape.S, 0, &tr)) return tk;
+    idx = make_room(t);
+    if (idx < 0) return tk;
     PolicyInput in;
-    in.M = (uint32_t)m;
-    in.N = (uint32_t)n;
+    in.M = (uint32_t)shape.m;
+    in.N = (uint32_t)shape.n;
     in.nkb = nkb;
     in.batch = 1;
     const Prediction r = policy_predict(tr, in, topology(device), cfg);
-    Entry e;
+    Entry &e = t.entries[(size_t)idx];
     e.key = key;
     const int model = r.breg ? 5 : (int)r.pick;
     e.slot[0] = model;
@@ -203,13 +251,16 @@ TuneTicket tuner_begin(const void *owner, int device, int S, size_t m, size_t n,
       e.decided = true;
       e.winner = model;
     }
-    t.entries.push_back(e);
-    idx = (int)t.entries.size() - 1;
+    t.index.emplace(key, idx);
   }
   Entry &e = t.entries[(size_t)idx];
-  if (e.decided && e.phase == 0 && e.ncand > 1 && ++e.calls >= TUNE_RECHECK_CALLS) {
-    e.phase = 1; // (nothing of this entry is in flight: a decision needs every asked-for sample collected)
-    e.decided = false;
+  e.last_use = ++t.tick;
+  if (e.seen < (1 << 30)) e.seen++;
+  if (e.ncand > 1 && !e.decided && e.measurements == 0 && e.issued == 0 && e.seen < sw.first_call) {
+    return tk; // not worth a measurement yet: no override (the model's pick), no event
+  }
+  if (e.decided && e.ncand > 1 && ++e.calls >= e.recheck_after) {
+    e.decided = false; // (nothing of this entry is in flight: a decision needs every asked-for sample collected)
     e.issued = 0;
     for (int c = 0; c < e.ncand; c++) e.samples[c] = 0;
   }
@@ -217,18 +268,21 @@ TuneTicket tuner_begin(const void *owner, int device, int S, size_t m, size_t n,
     policy_override(e.winner);
     return tk;
   }
-  if (e.issued >= TUNE_ROUNDS * e.ncand || t.pending.size() >= TUNE_MAX_PENDING) {
-    policy_override(e.winner >= 0 ? e.winner : e.slot[0]); // everything asked for is in flight: the first decision (or the model's pick)
+  if (e.issued >= TUNE_ROUNDS * e.ncand || t.pending.size() >= TUNE_MAX_PENDING || !fill_pool(t) || t.pool.size() < 2) {
+    policy_override(e.winner >= 0 ? e.winner : e.slot[0]); // everything asked for is in flight: the last decision (or the model's pick)
     return tk;                                              // until the times are in
   }
-  // round r times every candidate once, starting with candidate r (the first call of a shape runs the model's pick)
+  // round r times every candidate once, starting with candidate r (the first sample of a measurement is the model's pick)
   const int round = e.issued / e.ncand, c = (e.issued % e.ncand + round) % e.ncand;
-  hipEvent_t ev0 = take_event(t), ev1 = ev0 ? take_event(t) : nullptr;
-  if (!ev1 || hipEventRecord(ev0, stream) != hipSuccess) {
+  hipEvent_t ev0 = t.pool.back();
+  t.pool.pop_back();
+  hipEvent_t ev1 = t.pool.back();
+  t.pool.pop_back();
+  if (hipEventRecord(ev0, stream) != hipSuccess) {
     (void)hipGetLastError();
-    if (ev0) t.pool.push_back(ev0);
-    if (ev1) t.pool.push_back(ev1);
-    policy_override(e.slot[0]);
+    t.pool.push_back(ev0);
+    t.pool.push_back(ev1);
+    policy_override(e.winner >= 0 ? e.winner : e.slot[0]);
     return tk;
   }
   e.issued++;
@@ -240,17 +294,13 @@ TuneTicket tuner_begin(const void *owner, int device, int S, size_t m, size_t n,
   tk.start = ev0;
   tk.stop = ev1;
   tk.stream = stream;
-  tk.owner = owner;
   return tk;
 }
 
-void tuner_end(TuneTicket &tk, bool ok) {
+void tuner_end(Tuner *tp, TuneTicket &tk, bool ok) {
   policy_override(-1);
-  if (tk.entry < 0) return;
-  std::lock_guard<std::mutex> lock(g_mtx);
-  auto it = g_tuners.find(tk.owner);
-  if (it == g_tuners.end()) return;
-  Tuner &t = it->second;
+  if (tk.entry < 0 || !tp) return;
+  Tuner &t = *tp;
   if (ok && hipEventRecord(tk.stop, tk.stream) == hipSuccess) {
     t.pending.push_back(Pending{tk.entry, tk.cand, tk.counts, tk.start, tk.stop});
   } else {
@@ -264,32 +314,36 @@ void tuner_end(TuneTicket &tk, bool ok) {
   tk.entry = -1;
 }
 
-void tuner_forget(const void *owner) {
-  std::lock_guard<std::mutex> lock(g_mtx);
-  auto it = g_tuners.find(owner);
-  if (it == g_tuners.end()) return;
-  for (Pending &p : it->second.pending) {
+void tuner_forget(Tuner *&tp) {
+  if (!tp) return;
+  for (Pending &p : tp->pending) {
     (void)hipEventDestroy(p.start);
     (void)hipEventDestroy(p.stop);
   }
-  for (hipEvent_t e : it->second.pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : tp->pool) (void)hipEventDestroy(e);
   (void)hipGetLastError();
-  g_tuners.erase(it);
+  delete tp;
+  tp = nullptr;
 }
 
-int tuner_state(const void *owner, int S, size_t m, size_t n, size_t k, int *slot, int *candidates) {
-  std::lock_guard<std::mutex> lock(g_mtx);
-  auto it = g_tuners.find(owner);
-  if (it == g_tuners.end()) return -1;
-  collect(it->second);
-  const Key key{S, m, n, k};
-  for (const Entry &e : it->second.entries)
-    if (e.key == key) {
-      if (slot) *slot = e.decided ? e.winner : -1;
-      if (candidates) *candidates = e.ncand;
-      return e.decided ? 1 : 0;
-    }
-  return -1;
+int tuner_state(Tuner *tp, int S, int op_a, int op_b, int beta_nonzero, size_t m, size_t n, size_t k, int out[4]) {
+  if (!tp) return -1;
+  collect(*tp);
+  const Entry *hit = nullptr;
+  for (const Entry &e : tp->entries) {
+    const Key &x = e.key;
+    if (e.ncand == 0 || x.S != S || x.m != m || x.n != n || x.k != k) continue;
+    if (op_a >= 0 && (x.op_a != op_a || x.op_b != op_b || x.beta_nz != (beta_nonzero ? 1 : 0))) continue;
+    if (!hit || e.last_use > hit->last_use) hit = &e;
+  }
+  if (!hit) return -1;
+  if (out) {
+    out[0] = hit->decided ? hit->winner : -1;
+    out[1] = hit->ncand;
+    out[2] = hit->seen;
+    out[3] = hit->measurements;
+  }
+  return hit->decided ? 1 : 0;
 }
 
 } // namespace ozhip

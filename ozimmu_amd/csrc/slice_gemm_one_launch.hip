@@ -28,8 +28,12 @@
 //
 // No deadlock by construction: a workgroup that has polled `spin` times without seeing a strip cuts that strip ITSELF - the
 // cut is a pure function of the operand, so a second writer stores the same bytes - and goes on.  If fewer CUs than
-// workgroups are available (CU masks, a partition the topology probe does not know) the launch degrades to "every workgroup
-// cuts what it needs" instead of hanging.
+// workgroups are available (CU masks, a partition the topology probe does not know, another stream's kernels holding CUs) the
+// launch degrades to "every workgroup cuts what it needs" instead of hanging.  The wait is bounded by what it waits FOR
+// (ADVICE r5): a poll is an agent-scope load + s_sleep, ~1 us, and the owners' cuts take 10-14 us in all, so the default of
+// 96 polls is several times the longest legitimate wait; and a workgroup that has timed out ONCE stops waiting - its owner
+// is evidently not resident - and cuts every strip it still misses after a single look (the counter used to restart per
+// strip: 16 strips x 20 000 polls = hundreds of ms on CUs other work was waiting for).  Worst case now: ~0.1 ms + 16 cuts.
 //
 // Results: bit-identical to the two-launch form (same cut, same tile function, same epilogue).
 #include <hip/hip_runtime.h>
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(512, 1) void split_gemm_k2_kernel(const SliceGemmAr
   auto strip_of = [&](uint32_t i) { return i < 8u ? tm * 8u + i : nblk0 + tn * 8u + (i - 8u); };
   uint32_t s = blockIdx.x;
   bool own = s < total;
+  uint32_t patience = spin; // polls before self-service; 1 after the first timeout
 #pragma unroll 1
   for (;;) {
     if (!own) {
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void split_gemm_k2_kernel(const SliceGemmAr
           miss = __ballot(!ok);
           if (!miss) break;
           __builtin_amdgcn_s_sleep(2);
-        } while (++spins < spin);
+        } while (++spins < patience);
         if (lane == 0) wg_miss = (unsigned)miss;
       }
       __syncthreads();
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(512, 1) void split_gemm_k2_kernel(const SliceGemmAr
       if (!miss) break;
       __syncthreads(); // everybody has read wg_miss before wave 0 writes the next round's
       s = strip_of((uint32_t)__ffs(miss) - 1u); // not seen in time: cut it here (same bytes as its owner writes)
+      patience = 1u;
     }
     cut_strip(s);
     if (own) {
@@ -166,7 +172,7 @@ struct OneLaunchCfg {
   uint32_t spin;
 };
 static OneLaunchCfg one_launch_cfg() {
-  auto read = []() { return OneLaunchCfg{(int)env_number("OZIMMU_HIP_ONE_LAUNCH", 1), (uint32_t)env_number("OZIMMU_HIP_ONE_LAUNCH_SPIN", 20000)}; };
+  auto read = []() { return OneLaunchCfg{(int)env_number("OZIMMU_HIP_ONE_LAUNCH", 1), (uint32_t)std::max(1l, env_number("OZIMMU_HIP_ONE_LAUNCH_SPIN", 96))}; };
   if (config().env_per_call) return read();
   static const OneLaunchCfg c = read();
   return c;

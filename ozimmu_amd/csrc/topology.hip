@@ -42,6 +42,34 @@ __global__ __launch_bounds__(256) void mfma_calibration_kernel(int iters, int *s
   if (s == 0x12345678) sink[0] = s;
 }
 
+// bench.py's roofline.frac_of_measured_mfma_ceiling: what the matrix pipe alone sustains on THIS part, now -
+// v_mfma_i32_16x16x64_i8 (the headline kernel's instruction), 24 independent accumulators, every operand bit random, four
+// waves per SIMD, no memory traffic.  The part is power limited under this load (profiles/r3_power_bound.md: 3 948 TOPS =
+// 0.784 of the 5 033 nominal), so the ceiling has to be measured in steady state: launches of ~10 ms for `seconds`, the
+// last 60 % timed.
+__global__ __launch_bounds__(256) void mfma_ceiling_kernel(int iters, int *sink) {
+  tv4i a[9], b[9];
+  unsigned x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 777u;
+  for (int i = 0; i < 9; i++) {
+    for (int c = 0; c < 4; c++) {
+      x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+      a[i][c] = (int)x;
+      b[i][c] = (int)(x * 2654435761u);
+    }
+    asm volatile("" : "+v"(a[i]), "+v"(b[i]));
+  }
+  tv4i acc[24];
+  for (int i = 0; i < 24; i++)
+    for (int r = 0; r < 4; r++) acc[i][r] = 0;
+  for (int it = 0; it < iters; it++)
+#pragma unroll
+    for (int i = 0; i < 24; i++) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i % 9], b[(i * 5 + 1) % 9], acc[i], 0, 0, 0);
+  int s = 0;
+  for (int i = 0; i < 24; i++)
+    for (int r = 0; r < 4; r++) s += acc[i][r];
+  if (s == 0x12345678) sink[0] = s;
+}
+
 static std::mutex g_mtx;
 static Topology g_topo[64];
 
@@ -115,3 +143,37 @@ void probe_topology(int dev) {
 }
 
 } // namespace ozhip
+
+extern "C" int ozimmu_hip_mfma_ceiling(int device, double seconds, double *tops) {
+  if (!tops || !(seconds > 0) || seconds > 30.0) return 1;
+  int cur = 0, cus = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return 3;
+  if (device < 0) device = cur;
+  if (device != cur && hipSetDevice(device) != hipSuccess) return 3;
+  int rc = 3;
+  int *d = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0 &&
+      hipMalloc((void **)&d, 256) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    const int iters = 12000; // ~10 ms per launch
+    const int launches = std::max(5, (int)(seconds / 0.010)), untimed = (launches * 2) / 5;
+    for (int i = 0; i < launches; i++) {
+      if (i == untimed) hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(ozhip::mfma_ceiling_kernel, dim3(4 * cus), dim3(256), 0, 0, iters, d);
+    }
+    hipEventRecord(e1, 0);
+    float ms = 0;
+    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) {
+      const double ops = 2.0 * 16384.0 * 24.0 * (double)iters * 4.0 * (4.0 * cus) * (double)(launches - untimed);
+      *tops = ops / ((double)ms * 1e-3) / 1e12;
+      rc = 0;
+    }
+  }
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  if (d) hipFree(d);
+  (void)hipGetLastError();
+  if (device != cur) hipSetDevice(cur);
+  return rc;
+}
+

@@ -29,8 +29,10 @@ def test_bench_line_under_torch_distributed_run_with_the_rccl_group():
                 "--force-dist", "--no-cpu", "--no-traffic", "--no-configs"], OZIMMU_BENCH_N="2048")
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1
     assert out["unit"] == "TFLOP/s" and out["higher_is_better"] is True and out["scaling"] == "weak"
-    # no published number: vs_baseline = the run's own alternating ratio against rocBLAS native DGEMM
-    assert out["vs_baseline"] == out["extra"]["interleaved_vs_rocblas_dgemm"]["ratio"] and "rocBLAS" in out["vs_baseline_is"]
+    # no published number: vs_baseline is null; the ratios against rocBLAS native DGEMM have their own keys
+    assert out["vs_baseline"] is None
+    assert out["vs_rocblas_dgemm_alternating"] == out["extra"]["interleaved_vs_rocblas_dgemm"]["ratio"]
+    assert out["vs_rocblas_dgemm_sequential"] == out["extra"]["speedup_vs_rocblas_dgemm"]
     assert abs(out["value"] - 2.0 * 2048 ** 3 / (out["ms_per_step"] * 1e-3) / 1e12) < 0.02 * out["value"]
     assert 20.0 < out["value"] < 200.0                      # fp64_int8_9 at 2048^3: ~54 TFLOP/s
     assert out["roofline"]["bound"] == "mfma" and 0.1 < out["roofline"]["frac"] < 1.0
@@ -49,6 +51,7 @@ def test_bench_default_line_has_the_contract_fields():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert out["extra"]["interleaved_vs_rocblas_dgemm"]["ratio"] > 0.5
-    assert out["vs_baseline"] == out["extra"]["interleaved_vs_rocblas_dgemm"]["ratio"]
+    assert out["vs_baseline"] is None and out["vs_rocblas_dgemm_alternating"] == out["extra"]["interleaved_vs_rocblas_dgemm"]["ratio"]
+    assert 0.5 < rf["frac_of_measured_mfma_ceiling"] < 1.05 and rf["measured_mfma_ceiling"] < rf["peak"]
     assert set(out["extra"]["short_k"]) == {"8192x8192x256", "8192x8192x512"}
     assert "1536" in out["extra"]["square_sizes_tflops"]

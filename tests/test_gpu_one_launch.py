@@ -181,3 +181,57 @@ def test_one_launch_equals_two_launches_under_churn(oz, monkeypatch):
             torch.cuda.synchronize()
     torch.cuda.synchronize()
     assert int(bad) == 0, f"{int(bad)} of {rounds} one-launch results differ from the two-launch form"
+
+
+def test_fewer_resident_workgroups_than_the_grid_degrades_within_a_time_bound(oz, monkeypatch):
+    """the launch assumes every workgroup resident.  On a CU-masked stream (hipExtStreamCreateWithCUMask: 32
+    of the device's CUs) 256 workgroups run 32 at a time: the resident ones wait for strips whose owners cannot start before
+    they finish.  With the DEFAULT spin count the launch must degrade to self-service within a few of its own durations - the
+    old default (20 000 polls per missing strip, the counter restarting after every self-cut) took hundreds of milliseconds -
+    and the result stays bit-exact."""
+    import ctypes
+    import torch
+    m_, h = oz
+    monkeypatch.setenv("OZIMMU_HIP_GEMM_KERNEL", "k2")
+    monkeypatch.setenv("OZIMMU_HIP_ONE_LAUNCH", "1")
+    monkeypatch.delenv("OZIMMU_HIP_ONE_LAUNCH_SPIN", raising=False)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (cus + 31) // 32
+    mask = (ctypes.c_uint32 * words)(*([0] * words))
+    mask[0] = 0xFFFFFFFF  # the first 32 CUs
+    stream = ctypes.c_void_p()
+    if hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), words, mask) != 0 or not stream.value:
+        pytest.skip("hipExtStreamCreateWithCUMask is not available on this box")
+    try:
+        m, n, k, S = 1024, 1024, 512, 9
+        rng = np.random.default_rng(99)
+        a = operand("N", m, k, rng)
+        b = operand("T", k, n, rng)
+        c = ColMajor(m, n)
+        c_ref = ColMajor(m, n)
+        assert O.gemm("N", "T", m, n, k, 1.0, a.view, b.view, 0.0, c_ref.view, S, O.ORDER_DIAGONAL) == 0
+        a.dev, b.dev, c.dev
+        torch.cuda.synchronize()
+        times = []
+        for it in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ext = torch.cuda.ExternalStream(stream.value)
+            e0.record(ext)
+            assert m_.gemm_on_stream(h, stream.value, "N", "T", m, n, k, 1.0, a.dev, a.ld, b.dev, b.ld, 0.0, c.dev, c.ld,
+                                     f"fp64_int8_{S}") == 0
+            e1.record(ext)
+            assert hip.hipStreamSynchronize(stream) == 0
+            assert m_.last_kernel(h)[0] == "k2_one_launch"
+            times.append(e0.elapsed_time(e1))
+            np.testing.assert_array_equal(c.download().view(np.uint64), c_ref.view.view(np.uint64))
+        # 256 tiles on 32 CUs are eight rounds of the tile function (~40 us each at full occupancy) + each round's bounded wait
+        # and self-service cuts: a few milliseconds at most.  The unbounded form: 8 rounds x up to 16 strips x 20-40 ms.
+        assert min(times) < 20.0, times
+    finally:
+        torch.cuda.synchronize()
+        m_.set_cuda_stream(h, None)
+        hip.hipStreamDestroy(stream)
