@@ -356,16 +356,17 @@ for line in sys.stdin:            # one "go" per repetition
 """
 
 
-def openblas_all_cores(x, y, threads_per_process):
-    """x @ y with the column panels of y spread over enough processes to put one BLAS thread on every logical CPU of the host
-    (os.cpu_count() / threads_per_process of them, at most 8); the repetitions start together, a repetition's time is its
+def openblas_all_cores(x, y, threads_per_process, procs=None):
+    """x @ y with the column panels of y spread over `procs` processes of `threads_per_process` BLAS threads each (default: enough
+    to put one thread on every logical CPU of the host, at most 8); the repetitions start together, a repetition's time is its
     slowest panel.  None when one process already covers the host."""
     import shutil
     import subprocess
     import tempfile
     import numpy as np
     ncpu = os.cpu_count() or 1
-    procs = max(1, min(8, ncpu // max(1, threads_per_process)))
+    if procs is None:
+        procs = max(1, min(8, ncpu // max(1, threads_per_process)))
     if procs < 2:
         return None
     tmp = tempfile.mkdtemp(prefix="ozbench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -716,14 +717,17 @@ def main():
                           f"{best:.2f} s"}
             # ... and on ALL host cores: the bundled OpenBLAS is built for at most 64 threads, so the same
             # product runs as column panels of B in several processes of `blas_threads` threads each, started together
+            # (one thread per logical CPU - 256 on the pool's hosts: 128 cores x SMT - and one per physical core; round 6 measured the
+            # former at a THIRD of the single 64-thread process: the panels fight over the memory system)
             try:
-                allc = openblas_all_cores(x, y, blas_threads)
-                if allc:
-                    out["cpu_baseline"]["openblas_dgemm_all_cores"] = dict(
-                        allc, unit="TFLOP/s", host_logical_cpus=os.cpu_count(), blas=blas_name,
-                        value=round(2.0 * M * N * K / allc["seconds"] / 1e12, 4))
+                full = max(1, min(8, (os.cpu_count() or 1) // max(1, blas_threads)))
+                for key, procs in (("openblas_dgemm_all_logical_cpus", full), ("openblas_dgemm_all_physical_cores", full // 2)):
+                    allc = openblas_all_cores(x, y, blas_threads, procs) if procs >= 2 else None
+                    if allc:
+                        out["cpu_baseline"][key] = dict(allc, unit="TFLOP/s", host_logical_cpus=os.cpu_count(), blas=blas_name,
+                                                        value=round(2.0 * M * N * K / allc["seconds"] / 1e12, 4))
             except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"]["openblas_dgemm_all_cores"] = {"error": repr(e)}
+                out["cpu_baseline"]["openblas_dgemm_all_cores_error"] = repr(e)
 
         if not args.no_extra and not args.no_configs and world == 1 and "extra" in out:
             # the other BASELINE configs and a ZGEMM next to rocBLAS (needs ~20 GB of HBM: the headline tensors go first)

@@ -192,9 +192,16 @@ __device__ __forceinline__ void gload16_named_accn(const int8_t *sbase, uint32_t
   OZ_ACCN_ASM_MEM(CL, "global_load_dwordx4 v[%c0:%c1], %2, %3 offset:%c4", : "i"(REG), "i"(REG + 3), "v"(voff), "s"(sbase), "i"(IMM));
 }
 // accumulator tuple X += b x a.  BREG_ < 0: the B fragment is the compiler's value `b`; else v[BREG_ : BREG_ + 3]
-template <int CL, int X, int BREG_>
+template <int CL, int X, int BREG_, bool ZC = false> // ZC: the tuple is WRITTEN (C = 0): the first MFMA of a tile on it
 __device__ __forceinline__ void mfma16_accn(const v4i &b, const v4i &a) {
-  if constexpr (X < 64) {
+  if constexpr (ZC) {
+    static_assert(BREG_ >= 0, "the zeroing form exists for the register kernel");
+    if constexpr (X < 64)
+      OZ_ACCN_ASM(CL, "v_mfma_i32_16x16x64_i8 a[%c0:%c1], v[%c2:%c3], %4, 0", : "i"(4 * X), "i"(4 * X + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a));
+    else
+      OZ_ACCN_ASM(CL, "v_mfma_i32_16x16x64_i8 v[%c0:%c1], v[%c2:%c3], %4, 0",
+                  : "i"(accn_v_first(CL) + 4 * (X - 64)), "i"(accn_v_first(CL) + 4 * (X - 64) + 3), "i"(BREG_), "i"(BREG_ + 3), "v"(a));
+  } else if constexpr (X < 64) {
     if constexpr (BREG_ < 0)
       OZ_ACCN_ASM(CL, "v_mfma_i32_16x16x64_i8 a[%c0:%c1], %2, %3, a[%c0:%c1]", : "i"(4 * X), "i"(4 * X + 3), "v"(b), "v"(a));
     else
@@ -230,6 +237,63 @@ __device__ __forceinline__ int read_accn(int x, int v) {
     OZ_ACCN_ASM(CL, "v_mov_b32 %0, v%c1", "=v"(r) : "i"(accn_v_first(CL) + 4 * (x - 64) + v));
   return r;
 }
+
+// ---- the recombination stream of the overlapped last step (slice_gemm_y_tile.h, round 6) as asm statements ---------------------
+// hipcc orders plain C++ conversions and fmas by register pressure, not by the source: written as `x = fma((double)r, sc, x)` the
+// stream's conversions and accumulations of six of a block's eight outputs sank to the block's end, one dependent chain (and the
+// scale constants went through v_readlane spills).  As asm statements they stay where the schedule puts them; the accumulator
+// read rides in the MFMA's own statement (no compiler-inserted wait state between the two).
+// One MFMA slot of the overlapped step as ONE statement (hipcc puts an `s_nop` behind every asm statement it cannot look into: as
+// separate statements a slot was MFMA, read, nop, fma, cvt, nop - six issue slots against the MFMA's 16 cycles; the wave was
+// issue bound at ~37 cycles per slot, profiles/r6_ablate/):
+//   [accumulator tuple X += v[BREG_ : BREG_ + 3] x a]              (X < 0: no MFMA - the serial part of the stream)
+//   [rd = register RS of the accumulator file]                     (RS < 0: none; RS < 256: AGPR a[RS]; else VGPR v[RS - 256])
+//   [x = ldexp(fs, E) | x += 2^E * fs]                             (ACC 1: the chain's first fma(fs, 2^E, 0), exactly; 2: one rounding)
+//   [cv = double(cs)]
+// 2^E travels as the high word of a double literal (the low word of a power of two is zero: a VOP2 literal).  rd, cv and x are
+// read-write operands in every variant: a variant that does not write one leaves it alone.
+#define OZ_T_MFMA_A "v_mfma_i32_16x16x64_i8 a[%c3:%c4], v[%c5:%c6], %7, a[%c3:%c4]\n\t"
+#define OZ_T_MFMA_V "v_mfma_i32_16x16x64_i8 v[%c3:%c4], v[%c5:%c6], %7, v[%c3:%c4]\n\t"
+#define OZ_T_MFMA_N ""
+#define OZ_T_RD_A "v_accvgpr_read_b32 %0, a%c8\n\t"
+#define OZ_T_RD_V "v_mov_b32 %0, v%c8\n\t"
+#define OZ_T_RD_N ""
+#define OZ_T_F_1 "v_ldexp_f64 %2, %10, %c11\n\t"
+#define OZ_T_F_2 "v_fmac_f64_e32 %2, %c11, %10\n\t"
+#define OZ_T_F_0 ""
+#define OZ_T_C_1 "v_cvt_f64_i32_e32 %1, %9\n\t"
+#define OZ_T_C_0 ""
+#define OZ_EPI_CASE(M, MC, R, RC, F, C)                                                                                          \
+  else if constexpr (mk == MC && rk == RC && ACC == F && CVT == (C != 0)) OZ_ACCN_ASM(                                            \
+      CL, OZ_T_MFMA_##M OZ_T_RD_##R OZ_T_F_##F OZ_T_C_##C, "+v"(rd), "+v"(cv), "+v"(x)                                             \
+      : "i"(X0), "i"(X0 + 3), "i"(BREG_ < 0 ? 0 : BREG_), "i"(BREG_ < 0 ? 3 : BREG_ + 3), "v"(a), "i"(R0), "v"(cs), "v"(fs), "i"(ACC == 1 ? E : HI))
+#define OZ_EPI_CASES_FC(M, MC, R, RC)                                                                                             \
+  OZ_EPI_CASE(M, MC, R, RC, 0, 0);                                                                                                \
+  OZ_EPI_CASE(M, MC, R, RC, 0, 1);                                                                                                \
+  OZ_EPI_CASE(M, MC, R, RC, 1, 0);                                                                                                \
+  OZ_EPI_CASE(M, MC, R, RC, 1, 1);                                                                                                \
+  OZ_EPI_CASE(M, MC, R, RC, 2, 0);                                                                                                \
+  OZ_EPI_CASE(M, MC, R, RC, 2, 1)
+#define OZ_EPI_CASES_R(M, MC)                                                                                                     \
+  OZ_EPI_CASES_FC(M, MC, N, 0);                                                                                                   \
+  OZ_EPI_CASES_FC(M, MC, A, 1);                                                                                                   \
+  OZ_EPI_CASES_FC(M, MC, V, 2)
+template <int CL, int X, int BREG_, int RS, bool CVT, int ACC, int E>
+__device__ __forceinline__ void epi_slot_asm(const v4i &a, int &rd, double &cv, const int &cs, double &x, const double &fs) {
+  constexpr int mk = X < 0 ? 0 : X < 64 ? 1 : 2, rk = RS < 0 ? 0 : RS < 256 ? 1 : 2;
+  constexpr int X0 = X < 0 ? 0 : X < 64 ? 4 * X : accn_v_first(CL) + 4 * (X - 64), R0 = RS < 0 ? 0 : RS < 256 ? RS : RS - 256;
+  constexpr int HI = (1023 + E) << 20;
+  static_assert(E > -1000 && E < 1000 && (ACC != 1 || (E >= -16 && E <= 64)), "exponent as an inline constant / a normal double");
+  static_assert(X < 0 || BREG_ >= 0, "the MFMA of a slot takes its B fragment from the named registers");
+  if constexpr (mk == 0 && rk == 0 && ACC == 0 && !CVT) {
+  }
+  OZ_EPI_CASES_R(N, 0);
+  OZ_EPI_CASES_R(A, 1);
+  OZ_EPI_CASES_R(V, 2);
+}
+#undef OZ_EPI_CASES_R
+#undef OZ_EPI_CASES_FC
+#undef OZ_EPI_CASE
 
 // MFMA slots of one k-step of a wave that owns WA blocks: block a outermost, A slice i ascending, B slice j descending
 // over the pairs with D0 <= i + j < D0 + ND, i + j <= S - 1
@@ -285,13 +349,14 @@ constexpr int VARW_B1 = 1024;      // ONE wave-private B buffer instead of two (
 constexpr int VARW_HALF_BARRIERS = 2048; // measurement, WRONG RESULTS: the per-step barrier on every second k-step only
 constexpr int VARW_EPI_NOSTORE = 256; // measurement: epilogue without its stores
 constexpr int VARW_EPI_NOCHAIN = 512; // measurement: epilogue without its FP64 chains
-constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..107 of the first 32 workgroups -> p.acc
+constexpr int VARW_TRACE = 64;     // measurement: cycle stamps of k-steps 100..107 of the first 32 workgroups -> p.acc; k64 tile: wall-clock stamps of every tile's phases (slice_gemm_y_tile.h)
 constexpr int VARW_BAND4 = 16;     // measurement: XCD patch of 4 (M) x 8 (N) tiles instead of 8 x 4
 constexpr int VARW_BAND16 = 32;    // measurement: 16 x 2
 constexpr int VARW_K64 = 8192;     // k64 tile: v_mfma_i32_16x16x64_i8, one slice product over 64 k per instruction (slice_gemm_y_tile.h)
 constexpr int VARW_BREG = 16384;   // k64 tile: B fragments global -> VGPR (two register sets) instead of through a wave-private LDS stage
 constexpr int VARW_ACCN = 32768;   // k64 tile: the accumulators are NAMED registers (a[0:255] + v[160:255]), not compiler values (slice_gemm_y_tile.h)
 constexpr int VARW_BHI = 65536;    // k64 tile: the B slices j >= 9 global -> named VGPRs, refilled IN PLACE behind their last use; the rest through LDS
+constexpr int VARW_ZFILL = 131072; // k64 register kernel: zero the accumulators in front of the tile instead of letting its first step write them (the multi-product kernels: slice_gemm_y_tile.h)
 constexpr int VARW_X16 = 4096;     // paired tile: v_mfma_i32_16x16x64_i8, two slice products per instruction (slice_gemm_x_tile.h)
 
 // One output tile of (32*WA) x 128: rows start at A row-block rb0, columns at B row-block 4*tn.
@@ -673,6 +738,16 @@ __device__ __forceinline__ void band_order(uint32_t lid, uint32_t rows, uint32_t
 // same C in the given order, every claimed tile walked through all of them before the next tile is claimed - each
 // element of C sees the same sequence of updates as with one launch per product).  Geometry, queues and phase hints are
 // those of g[0].
+// The barriers of the tile loop order LDS traffic only (the previous tile's fragment reads against the claim's two words, the words
+// against the next tile's staging).  __syncthreads() also drains vmcnt - i.e. waits for the tile's stores of C to be acknowledged
+// (~0.5 us, profiles/r6_ablate/: "claim + entry") although nothing that follows depends on them: the next tile's prologue issues
+// for 2 us before its own vmcnt(0).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0, int DMAE, int TAIL_, bool MULTI>
 __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int count, char *smem) {
   const SliceGemmArgs &p = g[0];
@@ -680,7 +755,7 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
     constexpr int W = decltype(wa_tag)::value;
     auto one = [&](const SliceGemmArgs &q) {
       if constexpr ((VARW & VARW_K64) != 0)
-        y_tile<S, D0, ND, W, VARW & ~VARW_K64, STAG, DMA0, DMAE, TAIL_, OZ_Y_RING>(q, smem, rb0, c, xcd, hook);
+        y_tile<S, D0, ND, W, (VARW & ~VARW_K64) | (MULTI ? VARW_ZFILL : 0), STAG, DMA0, DMAE, TAIL_, OZ_Y_RING>(q, smem, rb0, c, xcd, hook);
       else if constexpr ((VARW & VARW_X16) != 0)
         x_tile<S, D0, ND, W, VARW & ~VARW_X16, STAG, DMA0, DMAE, TAIL_>(q, smem, rb0, c, xcd);
       else
@@ -711,7 +786,7 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
   // speculative claim (see below): only the k64 kernels with at most 320 accumulator registers carry its five extra live
   // values through their k loop without spilling (the 432 / 448-register kernels flip into scratch on ONE more: DESIGN.md 4.2)
   constexpr bool SPECULATE = !MULTI && (VARW & VARW_K64) != 0 && 2 * WA * 2 * ND * 4 <= 320 &&
-                             (VARW & (VARW_TRACE | VARW_NO_GLOBAL | VARW_MFMA_ONLY)) == 0;
+                             (VARW & (VARW_NO_GLOBAL | VARW_MFMA_ONLY)) == 0; // (the tile-boundary trace of the k64 tile keeps it)
   uint32_t spec_region = 0, spec_from = 0, spec_len = 0, spec_start = 0, spec_t = 0; // meaningful in thread 0 only
   uint32_t *spec_cnt = nullptr;
   // The ticket of the NEXT tile is drawn inside the current tile's prologue (y_tile: prologue_hook), between the issue of the
@@ -744,7 +819,7 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
         lid = xcd_run_start((xcd + nx - small_shift) % nx, nsmall, nx) + (idx - nbig_x);
       }
     } else {
-      __syncthreads(); // the previous tile's LDS reads are done
+      lds_barrier(); // the previous tile's LDS reads are done
       if (threadIdx.x == 0) {
         uint32_t k = 0, l = 0;
         if constexpr (SPECULATE) {
@@ -787,10 +862,10 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
           spec_region = (k && spec_from == k && p.kb1 - p.kb0 <= p.spec_claim_kb) ? k : 0u;
         }
       }
-      __syncthreads();
+      lds_barrier();
       kind = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile uint32_t *>(smem)[0]);
       lid = __builtin_amdgcn_readfirstlane(reinterpret_cast<volatile uint32_t *>(smem)[1]);
-      __syncthreads(); // smem is staging space again
+      lds_barrier(); // smem is staging space again
       if (!kind) break;
     }
     uint32_t r, c;

@@ -38,6 +38,7 @@ struct YSched {
   int ns = 0, ng = 0;
   int sa[MAXS] = {}, si[MAXS] = {}, sj[MAXS] = {}, sb[MAXS] = {}, sg[MAXS] = {};
   int gfirst[MAXG] = {}, g_a[MAXG] = {}, g_i[MAXG] = {};
+  bool first[MAXS] = {}; // the slot is the step's first MFMA on its accumulator tuple (block, column block, diagonal)
   constexpr YSched() {
     for (int a = 0; a < MA; a++)
       for (int i = 0; i < S; i++) {
@@ -57,6 +58,11 @@ struct YSched {
         }
         if (any) ng++;
       }
+    for (int q = 0; q < ns; q++) {
+      first[q] = true;
+      for (int r = 0; r < q; r++)
+        if (sa[r] == sa[q] && sb[r] == sb[q] && si[r] + sj[r] == si[q] + sj[q]) first[q] = false;
+    }
   }
   constexpr int max_j_from(int s0) const {
     int m = 0;
@@ -121,6 +127,50 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // ---- VARW_TRACE (tools/gemm_ablate.hip -DABLATE_TILE_TRACE only): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of
+  // every tile a workgroup runs -> p.acc, which a single-pass launch does not use otherwise.  0: tile entry (ticket in hand),
+  // 1: first stage's copies issued + the next ticket drawn, 2: first stage landed and the barrier passed (k loop starts),
+  // 3: in front of the last step, 4: behind it, 5: epilogue issued (p.dump_only & 1: and its stores drained), + the shader
+  // cycles (s_memtime) at 0 and 5.  A stamp waits for the scalar memory path (lgkmcnt(0)): a few tens of cycles each.
+  constexpr bool TTRACE = (VARW & VARW_TRACE) != 0;
+  unsigned long long tt[TTRACE ? 6 : 1] = {}, tcyc[TTRACE ? 2 : 1] = {};
+  auto tstamp = [&](auto ic) {
+    if constexpr (TTRACE) {
+      unsigned long long t;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      tt[decltype(ic)::value] = t;
+    }
+  };
+  auto tcycles = [&](auto ic) {
+    if constexpr (TTRACE) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      tcyc[decltype(ic)::value] = t;
+    }
+  };
+  auto tflush = [&](bool overlapped) {
+    if constexpr (TTRACE) {
+      if (p.dump_only & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tstamp(std::integral_constant<int, 5>{});
+      tcycles(std::integral_constant<int, 1>{});
+      if (threadIdx.x == 0) {
+        unsigned long long *base = reinterpret_cast<unsigned long long *>(p.acc);
+        const unsigned long long seq = atomicAdd(base + blockIdx.x, 1ull);
+        if (seq < 40) {
+          unsigned long long *r = base + 16384 + ((size_t)blockIdx.x * 40 + seq) * 16;
+#pragma unroll
+          for (int i = 0; i < 6; i++) r[i] = tt[i];
+          r[6] = tcyc[0];
+          r[7] = tcyc[1];
+          r[8] = ((unsigned long long)rb0 << 32) | tn;
+          r[9] = (overlapped ? 1ull : 0ull) | ((unsigned long long)xcd << 8);
+        }
+      }
+    }
+  };
+  tstamp(std::integral_constant<int, 0>{});
+  tcycles(std::integral_constant<int, 0>{});
 
   // ---- staging: w_tile's, with runs of 2 * S blocks ------------------------------------------------------------
   const size_t rb_stride = (size_t)p.KB * (size_t)(S * FRAG_BYTES);
@@ -203,7 +253,15 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   constexpr int NACC = MA * 2 * ND, NACC_A = ACCN ? 1 : (NACC < 64 ? NACC : 64), NACC_V = (!ACCN && NACC > 64) ? NACC - 64 : 1;
   static_assert(!ACCN || NACC <= (BREG ? 72 : SL == 12 ? 96 : 88), "named accumulators: a[0:255] + v[160:255] (register form: + v[80:111])");
   v4i accA[NACC_A], accV[NACC_V];
-  if constexpr (ACCN) {
+  // (the register kernel never zeroes: the first MFMA of its first step on every tuple takes the constant 0 as C - 288
+  // v_accvgpr_write / v_mov in front of every tile were 0.6 us of a 2.4 us prologue that is all instruction issue,
+  // profiles/r6_ablate/r6d_tile_trace_*)
+  // (not in the multi-product kernels, VARW_ZFILL: with the peeled first steps next to its product loop hipcc's block placement turned
+  // their k loops irreducible and its wait insertion gave up on counted lgkmcnt waits there - a full LDS drain per fragment group;
+  // a ZGEMM's products never take the overlapped path either: they keep the round-5 shape of the tile function)
+  constexpr bool ZERO_BY_FIRST_STEP = BREG && ACCN && !MFMA_ONLY && (VARW & VARW_ZFILL) == 0;
+  if constexpr (ZERO_BY_FIRST_STEP) {
+  } else if constexpr (ACCN) {
     static_for<NACC>([&](auto xc) { zero_accn<CLK, decltype(xc)::value>(); });
   } else {
 #pragma unroll
@@ -224,10 +282,10 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     else
       mfma16_vgpr(accV[X - 64], b, a);
   };
-  auto mfma_named = [&](auto xc, auto reg, const v4i &a, auto cl) { // B operand in the named registers (VARW_BREG)
+  auto mfma_named = [&](auto xc, auto reg, const v4i &a, auto cl, auto zc) { // B operand in the named registers (VARW_BREG); zc: C = 0
     constexpr int X = decltype(xc)::value, REG = decltype(reg)::value;
     if constexpr (ACCN)
-      mfma16_accn<decltype(cl)::value, X, REG>(a, a);
+      mfma16_accn<decltype(cl)::value, X, REG, decltype(zc)::value>(a, a);
     else if constexpr (X < 64)
       mfma16_agpr_named<REG>(accA[X], a);
     else
@@ -308,6 +366,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     k_issue = koff_next(k_issue);
   }
   prologue_hook();
+  tstamp(std::integral_constant<int, 1>{});
   if constexpr (!NO_GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (!MFMA_ONLY) {
     __builtin_amdgcn_s_barrier();
@@ -320,6 +379,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     }
     static_for<(R < NG ? R : NG)>([&](auto gc) { read_a(gc, la0); });
   }
+  tstamp(std::integral_constant<int, 2>{});
   asm volatile("s_nop 7" ::: "memory"); // zero-fill -> first MFMA reading it as C
 
   uint32_t it = 0;
@@ -337,87 +397,146 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   // Round 5 first built this with the accumulators as compiler values: hipcc re-assigned 13 tuples between the k loop and this
   // step THROUGH SCRATCH (wrong sums, -10 %: profiles/r5_ablate/r5c_*).  With named accumulators there is nothing to re-assign; the
   // step lists only the second B set as clobbered (OZ_CL_P9_SET1), so the chain's values live in the first set's registers.
-  constexpr int EPU = ND + 3;                 // micro-operations per unit (column pair of a 16 x 16 block): begin, ND diagonals, scale, store
-  constexpr int EPB = 4 * EPU;                // ... per 16-row block: units (b, vp) = 2 column blocks x 2 column pairs
+  // Round 6 (profiles/r6_ablate/r6b_tile_trace_*): stamped per tile, the overlapped step took 7.0 us against 3.2 us of MFMA issue
+  // time - the chain hid almost nothing.  Its micro-operation was read -> convert -> fma on ONE temporary, twice: six
+  // instructions each waiting for the one before it (the compiler reuses the register), and an in-order wave that stalls on
+  // a VALU dependency does not issue its next MFMA either.  The chain is now a software pipeline over the block's 8 outputs
+  // per lane x ND diagonals = 8 ND elements e = (d, output): stream step t reads the accumulator of element t, converts
+  // element t - 2 and accumulates element t - 4 - three independent instructions per MFMA slot, every dependency two slots
+  // (>= 32 cycles) old, the fma of an output 8 slots behind its predecessor.  Same operations on every element in the same
+  // order (x = fma(double(c_d), 2^.., x), d ascending from fma(.., 0.0)): bit-identical.
+  constexpr int EPE = 8 * ND;                 // elements of a 16-row block per lane: (diagonal d, output o = 2 * unit + w), o fastest
   constexpr int SPA = NS / MA;                // MFMA slots per 16-row block
-  constexpr int EPI_T0 = 3;                   // first micro-operation this many slots into the next block (XDL write -> VALU read)
+  constexpr int EPI_T0 = 3;                   // first stream step this many slots into the next block (XDL write -> VALU read)
+  // unit u (column pair (b, vp) of the block) is complete behind stream step 8 (ND - 1) + 2 u + 1 + 4: scaled / stored at
+  constexpr int EPI_TAIL0 = EPI_T0 + 8 * (ND - 1) + 6, EPI_TAILD = 4; // slots TAIL0 + TAILD u (scale) and + 2 behind it (store)
   constexpr bool OVERLAP_BUILT = BREG && ACCN && SL == 9 && !NO_GLOBAL && !MFMA_ONLY && ((VARW >> 8) & 3) == 0 &&
-                                 (VARW & VARW_NO_EPILOGUE) == 0 && SPA * MA == NS && SPA >= EPB + EPI_T0 + 2;
+                                 (VARW & VARW_NO_EPILOGUE) == 0 && SPA * MA == NS && SPA > EPI_TAIL0 + 3 * EPI_TAILD + 2 &&
+                                 (VARW & VARW_ZFILL) == 0; // (the multi-product kernels run complex products only: never this form)
   const uint32_t e_mu = rb0 * 32u, e_nu = tn * 128u + (uint32_t)wave * 32u;
   bool overlap = false;
   if constexpr (OVERLAP_BUILT) {
-    overlap = p.epi_overlap && p.final && !p.cplx && !p.acc_in && e_mu + 16u * MA <= p.M && tn * 128u + 128u <= p.N &&
-              (p.ldc & 1u) == 0 && p.ldc < (1u << 26) && (reinterpret_cast<uintptr_t>(p.c) & 15u) == 0 && nk >= 2;
+    overlap = p.epi_overlap && p.L == 7 && p.final && !p.cplx && !p.acc_in && e_mu + 16u * MA <= p.M && tn * 128u + 128u <= p.N &&
+              (p.ldc & 1u) == 0 && p.ldc < (1u << 25) && (reinterpret_cast<uintptr_t>(p.c) & 15u) == 0 && nk >= 2;
 #ifdef OZIMMU_HIP_TEST_HOOKS
     overlap = overlap && !p.dump;
 #endif
   }
-  double e_sc[OVERLAP_BUILT ? ND : 1], e_ea[OVERLAP_BUILT ? MA : 1], e_eb[OVERLAP_BUILT ? 8 : 1];
-  double e_x0 = 0, e_x1 = 0, e_v0 = 0, e_v1 = 0;
+  double e_ea[OVERLAP_BUILT ? MA : 1], e_eb[OVERLAP_BUILT ? 8 : 1];
+  double e_xx[OVERLAP_BUILT ? 8 : 1] = {}, e_cv[3] = {0, 0, 0}, e_v0 = 0, e_v1 = 0;
+  int e_rd[3] = {0, 0, 0};
   double2 e_old[OVERLAP_BUILT ? 4 : 1];
   uint32_t e_boff = 0;
   bool e_odd = false, e_rmw = false;
-  auto e_colp = [&](uint32_t cofs, int A) { // wave-uniform: column nu + cofs (+ nl per lane, in e_boff), first row of block A
-    return reinterpret_cast<char *>(p.c + ((size_t)(e_nu + cofs) * p.ldc + e_mu)) + 128 * A;
+  // Addresses of C: a wave-UNIFORM 64-bit base (SGPR pair) + the lane's 32-bit byte offset e_boff, and the stores are asm
+  // statements in that form.  Written as plain pointer arithmetic, hipcc copied p.c into a VGPR pair at kernel entry, hoisted
+  // the lane's offset there too (both are invariant over the tile loop), SPILLED both - they live across k loops that leave it
+  // 80 registers - and reloaded them from scratch in front of every store of the overlapped step, each reload behind an
+  // `s_waitcnt vmcnt(0)` that also waits for the previous unit's store to retire: 16 memory round trips per tile, the whole
+  // 3.9 us by which the step exceeded its MFMA time in profiles/r6_ablate/r6b_tile_trace_* (rounds 5 and 6 alike).
+  // (and with the base spelled as a pointer expression it still did: the final add became a VALU add on a spilled VGPR copy of
+  // p.c.  The four column bases of a tile - unit u = column pair 16 (u >> 1) + 2 (u & 1) of the wave's 32 columns, block 0 - are
+  // therefore added up by SALU instructions in an asm statement, once per tile in epi_setup; a block is an immediate offset.)
+  uint32_t e_blo[4] = {0, 0, 0, 0}, e_bhi[4] = {0, 0, 0, 0};
+  auto e_colp = [&](int u) { // wave-uniform: first row of block 0 of unit u's first column (+ nl columns per lane, in e_boff)
+    return reinterpret_cast<const int8_t *>(((uint64_t)e_bhi[u] << 32) | e_blo[u]);
   };
   auto epi_setup = [&]() { // issued a block's worth of MFMAs ahead of the first use: exponents, the old C of block 0
-    const uint32_t nl = 4u * ((uint32_t)lane >> 4);
-    e_odd = (lane & 1) != 0;
+    // the lane id from the hardware, HERE: `lane` itself lives across the k loops in a scratch slot (its reload cost this step a
+    // full vmcnt drain), and what is computed from it must not be a loop invariant that is hoisted to the kernel's entry and spilled
+    uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ln));
+    const uint32_t nl = 4u * (ln >> 4);
+    e_odd = (ln & 1u) != 0;
     e_rmw = p.beta != 0.0;
-    e_boff = ((nl + ((uint32_t)lane & 1u)) * (uint32_t)p.ldc + ((uint32_t)lane & 14u)) * 8u;
+    e_boff = ((nl + (ln & 1u)) * (uint32_t)p.ldc + (ln & 14u)) * 8u; // (< 2^32: the overlapped form runs for ldc < 2^25)
 #pragma unroll
-    for (int d = 0; d < ND; d++) e_sc[d] = pow2d(46 - p.L * (D0 + d + 2));
-#pragma unroll
-    for (int a = 0; a < MA; a++) e_ea[a] = p.ea[e_mu + ((uint32_t)lane & 15u) + 16 * a];
+    for (int a = 0; a < MA; a++) e_ea[a] = p.ea[e_mu + (ln & 15u) + 16 * a];
     const double *eb_lane = p.eb + e_nu + nl;
 #pragma unroll
     for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int v = 0; v < 4; v++) e_eb[4 * b + v] = eb_lane[16 * b + v];
+    {
+      const uint64_t cb = (uint64_t)reinterpret_cast<uintptr_t>(p.c);
+      const uint32_t clo = __builtin_amdgcn_readfirstlane((uint32_t)cb), chi = __builtin_amdgcn_readfirstlane((uint32_t)(cb >> 32));
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint64_t off = ((uint64_t)(e_nu + 16u * (u >> 1) + 2u * (u & 1)) * p.ldc + e_mu) * 8u;
+        const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)off), ohi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
+        asm volatile("s_add_u32 %0, %2, %4\n\ts_addc_u32 %1, %3, %5" : "=&s"(e_blo[u]), "=&s"(e_bhi[u]) : "s"(clo), "s"(chi), "s"(olo), "s"(ohi) : "scc");
+      }
+    }
     if (e_rmw) {
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        e_old[u] = *reinterpret_cast<const double2 *>(e_colp(16 * (u >> 1) + 2 * (u & 1), 0) + (size_t)e_boff);
+      for (int u = 0; u < 4; u++) e_old[u] = *reinterpret_cast<const double2 *>(e_colp(u) + e_boff);
     }
   };
-  // micro-operation m of block A (compile-time indices); CLR: the clobber set of its accumulator reads
-  auto epi_micro = [&](auto a_tag, auto m_tag, auto cl_tag) {
-    constexpr int A = decltype(a_tag)::value, m = decltype(m_tag)::value, CLR = decltype(cl_tag)::value;
-    constexpr int u = m / EPU, q = m % EPU, b = u >> 1, vp = u & 1;
-    constexpr uint32_t cofs = 16 * b + 2 * vp;
+  // stream step t of block A (compile-time indices); CLR: the clobber set of its statements.  The read of element t is issued by
+  // the caller (fused with the slot's MFMA in the overlapped step: epi_read_reg names the register); here: convert element t - 2,
+  // accumulate element t - 4.  The scales 2^(46 - L (d + 2)) are literals: the overlapped form runs for L = 7 only (K <= 2^17).
+  auto epi_read_reg = [](auto a_tag, auto t_tag) constexpr { // accumulator register of element t of block A: AGPR index, or 256 + VGPR index
+    constexpr int A = decltype(a_tag)::value, t = decltype(t_tag)::value;
+    constexpr int d = t / 8, o = t % 8, u = o >> 1, b = u >> 1, vp = u & 1, x = (A * 2 + b) * ND + d, v = 2 * vp + (o & 1);
+    return x < 64 ? 4 * x + v : 256 + accn_v_first(OZ_CL_P9) + 4 * (x - 64) + v;
+  };
+  // slot t of the block behind block A (t - EPI_T0 = the stream step): [MFMA X with the B fragment in v[BR : BR + 3]] + the step's
+  // read / accumulate / convert, one statement (X < 0: the serial part behind the loop)
+  auto epi_stream = [&](auto a_tag, auto t_tag, auto cl_tag, auto x_tag, auto br_tag, const v4i &af_) {
+    constexpr int t = decltype(t_tag)::value - EPI_T0, CLR = decltype(cl_tag)::value;
+    constexpr int X = decltype(x_tag)::value, BR = decltype(br_tag)::value;
+    constexpr bool RD = t >= 0 && t < EPE, CVT = t >= 2 && t - 2 < EPE, ACCU = t >= 4 && t - 4 < EPE;
+    constexpr int e = ACCU ? t - 4 : 0, d = e / 8, o = e % 8;
+    constexpr int E = 46 - 7 * (D0 + d + 2);
+    constexpr int RS = RD ? epi_read_reg(a_tag, std::integral_constant<int, (RD ? t : 0)>{}) : -1;
+    epi_slot_asm<CLR, X, BR, RS, CVT, ACCU ? (d == 0 ? 1 : 2) : 0, E>(af_, e_rd[RD ? t % 3 : 0], e_cv[CVT ? (t - 2) % 3 : 0], e_rd[CVT ? (t - 2) % 3 : 0],
+                                                                      e_xx[o], e_cv[e % 3]);
+  };
+  // unit u of block A: scale (q = 0), then pair the lanes, alpha / beta, store (q = 1)
+  auto epi_tail = [&](auto a_tag, auto u_tag, auto q_tag) {
+    constexpr int A = decltype(a_tag)::value, u = decltype(u_tag)::value, q = decltype(q_tag)::value;
+    constexpr int b = u >> 1, vp = u & 1;
     if constexpr (q == 0) {
-      e_x0 = e_x1 = 0.0;
-    } else if constexpr (q <= ND) {
-      constexpr int d = q - 1, x = (A * 2 + b) * ND + d;
-      e_x0 = fma((double)read_accn<CLR>(x, 2 * vp), e_sc[d], e_x0);
-      e_x1 = fma((double)read_accn<CLR>(x, 2 * vp + 1), e_sc[d], e_x1);
-    } else if constexpr (q == ND + 1) {
       // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
-      e_v0 = e_x0 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp];
-      e_v1 = e_x1 * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp + 1];
+      e_v0 = e_xx[2 * u] * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp];
+      e_v1 = e_xx[2 * u + 1] * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp + 1];
     } else {
       const double s0 = lane_pair_swap(e_v0), s1 = lane_pair_swap(e_v1);
       double2 y;
       y.x = e_odd ? s1 : e_v0; // row 2i:     (column n from this lane | column n+1 from the even neighbour)
       y.y = e_odd ? e_v1 : s0; // row 2i + 1: (column n from the odd neighbour | column n+1 from this lane)
-      char *cp = e_colp(cofs, A) + (size_t)e_boff;
       if (e_rmw) {
         y.x = fma(p.alpha, y.x, p.beta * e_old[u].x);
         y.y = fma(p.alpha, y.y, p.beta * e_old[u].y);
         if constexpr (A + 1 < MA) // the old values of the next block's unit u: a block's worth of MFMAs ahead of their use
-          e_old[u] = *reinterpret_cast<const double2 *>(e_colp(cofs, A + 1) + (size_t)e_boff);
+          e_old[u] = *reinterpret_cast<const double2 *>(e_colp(u) + 128 * (A + 1) + e_boff);
       } else {
         y.x = p.alpha * y.x;
         y.y = p.alpha * y.y;
       }
-      *reinterpret_cast<double2 *>(cp) = y;
+      typedef double v2d_t __attribute__((ext_vector_type(2)));
+      const v2d_t yv = {y.x, y.y};
+      // (the wait state: a store of more than 8 bytes reads its data registers a cycle late, and the compiler does not
+      // look inside the statement - without it 0.08 % of the elements came out with the NEXT unit's values)
+      asm volatile("global_store_dwordx4 %0, %1, %2 offset:%c3\n\ts_nop 0" : : "v"(e_boff), "v"(yv), "s"(e_colp(u)), "i"(128 * A) : "memory");
     }
+  };
+  // the scale / store micro-operations of block A's units at slot t of the block behind it
+  auto epi_slot = [&](auto a_tag, auto t_tag) {
+    constexpr int t = decltype(t_tag)::value;
+    static_for<4>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (t == EPI_TAIL0 + EPI_TAILD * u) epi_tail(a_tag, uc, std::integral_constant<int, 0>{});
+      if constexpr (t == EPI_TAIL0 + EPI_TAILD * u + 2) epi_tail(a_tag, uc, std::integral_constant<int, 1>{});
+    });
   };
 
   // PAR (VARW_BREG): the register set this step multiplies out of; the next step's fragments are loaded into the other one
   // EPI: the overlapped last step (above)
-  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag, auto epi_tag) {
+  auto step = [&](auto pf_tag, auto nx_tag, auto par_tag, auto epi_tag, auto first_tag) {
     constexpr bool PF = decltype(pf_tag)::value, NX = decltype(nx_tag)::value, EPI = decltype(epi_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value; // the tile's first step of the register kernel: nothing has zeroed the accumulators
+    static_assert(!FIRST || (ZERO_BY_FIRST_STEP && !EPI), "the zeroing first step belongs to the register kernel");
     static_assert(!EPI || (!PF && !NX), "the overlapped last step prefetches nothing and meets no barrier");
     constexpr int PC = BREG ? decltype(par_tag)::value : 0, PN = BREG ? (PC ^ 1) : 0;
     const int abuf_n = abuf ^ 1;
@@ -461,9 +580,14 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
       constexpr int X = (a * 2 + b) * ND + (i + j);
       if constexpr (MFMA_ONLY)
         mfma(std::integral_constant<int, X>{}, cf[j], cf[i]);
+      else if constexpr (BREG && EPI && a >= 1) // + the recombination stream of block a - 1: read, accumulate, convert in the MFMA's statement
+        epi_stream(std::integral_constant<int, (a >= 1 ? a - 1 : 0)>{}, std::integral_constant<int, s - a * SPA>{}, std::integral_constant<int, OZ_CL_P9_SET1>{},
+                   std::integral_constant<int, X>{}, std::integral_constant<int, OZ_BREG_FIRST + ((PC * 2 + b) * SL + j) * 4>{},
+                   g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       else if constexpr (BREG)
         mfma_named(std::integral_constant<int, X>{}, std::integral_constant<int, OZ_BREG_FIRST + ((PC * 2 + b) * SL + j) * 4>{},
-                   g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R], std::integral_constant<int, EPI ? OZ_CL_P9_SET1 : OZ_CL_P9>{});
+                   g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R], std::integral_constant<int, EPI ? OZ_CL_P9_SET1 : OZ_CL_P9>{},
+                   std::integral_constant<bool, FIRST && YC.first[s]>{});
       else if constexpr (j >= SLB) // VARW_BHI: the fragment in its named registers
         mfma16_accn<CLK, X, BHI0 + (b * NHI + (j - SLB)) * 4>(af0, g == 0 ? af0 : af[(g >= 1 ? g - 1 : 0) % R]);
       else
@@ -474,13 +598,8 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
           epi_setup();
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (a >= 1) { // block a - 1 is final: its micro-operations spread over this block's slots
-          constexpr int t = s - a * SPA;
-          static_for<EPB>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
-            if constexpr (EPI_T0 + m * (SPA - EPI_T0 - 1) / EPB == t)
-              epi_micro(std::integral_constant<int, a - 1>{}, mc, std::integral_constant<int, OZ_CL_P9_SET1>{});
-          });
+        if constexpr (a >= 1) { // block a - 1 is final: its recombination stream runs through this block's slots
+          epi_slot(std::integral_constant<int, a - 1>{}, std::integral_constant<int, s - a * SPA>{});
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -537,38 +656,55 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using NO = std::false_type;
+    using ZF = std::integral_constant<bool, ZERO_BY_FIRST_STEP>; // the tile's first step writes the accumulators (C = 0)
     if constexpr (OVERLAP_BUILT) {
       if (overlap) {
+        step(std::true_type{}, std::true_type{}, P0{}, NO{}, ZF{});
+        it++;
         for (; it + 2 < nk;) {
-          step(std::true_type{}, std::true_type{}, P0{}, NO{});
+          step(std::true_type{}, std::true_type{}, P1{}, NO{}, NO{});
           it++;
-          step(std::true_type{}, std::true_type{}, P1{}, NO{});
+          step(std::true_type{}, std::true_type{}, P0{}, NO{}, NO{});
           it++;
         }
-        step(std::true_type{}, std::true_type{}, P0{}, NO{});
+        tstamp(std::integral_constant<int, 3>{});
+        step(NO{}, NO{}, P1{}, std::true_type{}, NO{}); // nothing prefetched, no barrier; blocks 0 .. MA-2 recombined and stored
         it++;
-        step(NO{}, NO{}, P1{}, std::true_type{}); // nothing prefetched, no barrier; blocks 0 .. MA-2 recombined and stored
-        it++;
+        tstamp(std::integral_constant<int, 4>{});
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulators
-        static_for<EPB>([&](auto mc) { epi_micro(std::integral_constant<int, MA - 1>{}, mc, std::integral_constant<int, OZ_CL_P9_ACC>{}); });
+        static_for<SPA>([&](auto tc) { // the last block's stream: the same steps, back to back
+          epi_stream(std::integral_constant<int, MA - 1>{}, tc, std::integral_constant<int, OZ_CL_P9_ACC>{}, std::integral_constant<int, -1>{},
+                     std::integral_constant<int, -1>{}, af0);
+          epi_slot(std::integral_constant<int, MA - 1>{}, tc);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        tflush(true);
         return;
       }
     }
-    for (; it < nk;) {
-      step(std::true_type{}, std::true_type{}, P0{}, NO{});
+    if constexpr (ZERO_BY_FIRST_STEP) {
+      step(std::true_type{}, std::true_type{}, P0{}, NO{}, ZF{});
       it++;
-      step(std::true_type{}, std::true_type{}, P1{}, NO{});
+      step(std::true_type{}, std::true_type{}, P1{}, NO{}, NO{});
+      it++;
+    }
+    for (; it < nk;) {
+      step(std::true_type{}, std::true_type{}, P0{}, NO{}, NO{});
+      it++;
+      step(std::true_type{}, std::true_type{}, P1{}, NO{}, NO{});
       it++;
     }
   } else {
     using P0 = std::integral_constant<int, 0>;
     using NO = std::false_type;
-    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{}, NO{});
+    for (; it + PD < nk; it++) step(std::true_type{}, std::true_type{}, P0{}, NO{}, NO{});
     if constexpr (PD > 1)
-      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{}, NO{});
-    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{}, NO{});
+      for (; it + 1 < nk; it++) step(std::false_type{}, std::true_type{}, P0{}, NO{}, NO{});
+    for (; it < nk; it++) step(std::false_type{}, std::false_type{}, P0{}, NO{}, NO{});
   }
 
+  tstamp(std::integral_constant<int, 3>{}); // (the plain form: the whole recombination lies behind the k loop, 3 = 4)
+  tstamp(std::integral_constant<int, 4>{});
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA -> VALU reads of its accumulator
   auto acc = [&](int a, int b, int d, int v) -> int {
     const int x = (a * 2 + b) * ND + d;
@@ -587,6 +723,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     return;
   }
   recombine_and_store16<D0, ND, MA, (VARW >> 8) & 3>(p, acc, rb0 * 32, tn * 128 + wave * 32);
+  tflush(false);
 #undef YC
 }
 

@@ -30,8 +30,13 @@ def test_blocked_lu_through_the_preload(native, mode):
     assert shim["taken"] == issued, (shim, issued)       # every trailing update ran here (thresholds = NB: all of them qualify)
     assert shim["seen"] == shim["taken"] + shim["declined"]
     assert sum(r["kernels"].values()) >= issued            # ... as slice-GEMM launches of this library
-    # FP64-grade: the Ozaki product's error (8.5e-17 relative at S = 9) is below the DGEMM's own rounding
-    assert r["backward_error"] <= 1.25 * native["backward_error"] + 1e-17, (r["backward_error"], native["backward_error"])
+    if mode == "fp64_int8_9":
+        # FP64-grade: the Ozaki product's error (8.5e-17 relative at S = 9) is below the DGEMM's own rounding
+        assert r["backward_error"] <= 1.25 * native["backward_error"] + 1e-17, (r["backward_error"], native["backward_error"])
+    else:
+        # threshold 1.5 (tools/lu_preload.py) selects fp64_int8_8 for these trailing matrices: one slice less, 2^7 coarser
+        # products, a factorisation ~7 x less accurate than the DGEMM's - what the threshold asks for, and far from 3 slices
+        assert r["backward_error"] <= 16 * native["backward_error"], (r["backward_error"], native["backward_error"])
     assert native["backward_error"] < 1e-13
 
 

@@ -296,7 +296,13 @@ def test_preload_falls_back_to_the_vendor_gemm_when_the_workspace_does_not_fit()
     assert p.returncode == 0, p.stdout + p.stderr
     assert "SAME_AS_VENDOR True" in p.stdout, p.stdout
     assert "falling back to the vendor GEMM" in p.stdout
-    assert "STATS1 [1, 0, 1, 0]" in p.stdout and "STATS2 [2, 1, 1, 0]" in p.stdout, p.stdout
+    # (a hipBLAS application reaches the shim twice when the Ozaki path declines: at the hipBLAS entry point and, through the
+    # vendor hipBLAS routine it is forwarded to, at the rocBLAS one - two attempts seen and declined for the one torch.mm)
+    import json
+    st1 = json.loads([l for l in p.stdout.splitlines() if l.startswith("STATS1")][0][len("STATS1 "):])
+    st2 = json.loads([l for l in p.stdout.splitlines() if l.startswith("STATS2")][0][len("STATS2 "):])
+    assert st1[0] in (1, 2) and st1 == [st1[0], 0, st1[0], 0], st1
+    assert st2 == [st1[0] + 1, 1, st1[0], 0], (st1, st2)
     diff = float([l for l in p.stdout.splitlines() if l.startswith("MAXDIFF")][0].split()[1])
     assert 0 < diff < 1e-9, diff       # the Ozaki result: not the vendor's bits, FP64-accurate (|C| ~ 1e2)
 

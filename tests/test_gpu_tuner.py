@@ -403,10 +403,14 @@ def test_samples_perturbed_by_another_stream_do_not_stand_for_ever(oz, monkeypat
         case.check()
         st, slot2, nc, seen, meas = m_.tuner_state(h, "fp64_int8_9", m, n, k, full=True)
         assert st == 1 and meas == 2 and SLOTS[slot2] in cand
-        t_decided = min(_timed(lambda: case.call(m_, h), 10) for _ in range(3))
-        monkeypatch.setenv("OZIMMU_HIP_AUTOTUNE", "0")
-        t_model = min(_timed(lambda: case.call(m_, h), 10) for _ in range(3))
-        assert t_decided <= 1.03 * t_model, (t_decided, t_model, SLOTS[slot], SLOTS[slot2], cand)
+        if SLOTS[slot2] != cand[0]:     # (deciding on the model's own pick needs no timing to be right)
+            t_decided, t_model = 1e30, 1e30
+            for _ in range(4):          # alternating legs: the part's clock drifts by several percent over seconds
+                monkeypatch.setenv("OZIMMU_HIP_AUTOTUNE", "1")
+                t_decided = min(t_decided, _timed(lambda: case.call(m_, h), 20))
+                monkeypatch.setenv("OZIMMU_HIP_AUTOTUNE", "0")
+                t_model = min(t_model, _timed(lambda: case.call(m_, h), 20))
+            assert t_decided <= 1.03 * t_model, (t_decided, t_model, SLOTS[slot], SLOTS[slot2], cand)
     finally:
         _sync()
         m_.destroy(h)

@@ -184,6 +184,9 @@ def test_product_and_test_flavour_kernels_differ_only_in_the_dump_branch():
     assert seen >= 60
 
 
+TILE_START = r"v_mfma_i32_16x16x64_i8 a\[32:35\], v\[112:115\], v\[\d+:\d+\], 0\s*$"
+
+
 def _varw(name):     # slice_gemm_w_[multi_]kernel<S, D0, ND, WA, VARW, ...>: the fifth template argument
     m = re.search(r"kernelILi\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", name)
     return int(m.group(1)) if m else 0
@@ -237,10 +240,17 @@ def test_named_b_registers_are_untouched_by_the_compiler(asm):
                     kinds.append((i, "load", 0))
                 elif re.search(r"v_accvgpr_write_b32 a0, 0", l):
                     kinds.append((i, "zero", 0))
+                # round 6: the register kernel does not zero its accumulators any more - the first MFMA of a tile on every tuple
+                # takes the constant 0 as C; a tile's very first MFMA (slot 0: block 0, slices i = 0, j = 8, column block 0 = tuple 8
+                # out of v[112:115]) marks the start of a tile function (it reads the first B set: the order of the checks matters)
+                if re.search(TILE_START, l):
+                    kinds[-1] = (i, "zero", 0)
             elif re.match(r"\s*(s_branch|s_endpgm|s_setpc)", l):
                 kinds.append((i, "zero", 0))   # not fall-through either: the overlapped path leaves the tile function here (the
                                                # plain k loop that follows in the text is the other side of a branch)
-        assert any("v_accvgpr_write_b32 a0, 0" in l for l in lines), f"{name}: no asm zero-fill (named accumulators expected)"
+        # (the multi-product kernels keep the zero-fill in front of the tile: slice_gemm_y_tile.h, VARW_ZFILL)
+        assert any(re.search(TILE_START, l) or "v_accvgpr_write_b32 a0, 0" in l for l in lines), \
+            f"{name}: neither a zeroing first MFMA nor an asm zero-fill (named accumulators expected)"
         in_asm = False
         for i, l in enumerate(lines):
             if "#ASMSTART" in l:
@@ -376,3 +386,62 @@ def test_one_launch_kernel_uses_no_cache_maintenance_and_no_scratch(tmp_path):
         assert "v_mfma_i32_32x32x32_i8" in body, name
     meta = re.findall(r"\.name:\s+_ZN5ozhip20split_gemm_k2_kernel\w+\n(?:.*\n)*?\s+\.private_segment_fixed_size: (\d+)", text)
     assert meta and all(int(x) == 0 for x in meta)
+
+
+def test_overlapped_last_step_is_free_of_scratch_and_compiler_waits(asm):
+    """Round 6 (profiles/r6_ablate/): the register kernel's overlapped last step - the recombination stream of block a - 1 fused into
+    the MFMA statements of block a - took the SUM of its MFMA time and the chain's time, because the compiler had hoisted the
+    lane's offset into C and a VGPR copy of the C pointer to the kernel's entry, spilled both and reloaded them from scratch,
+    behind an `s_waitcnt vmcnt(0)`, in front of every store.  The addresses are now a SALU-built uniform base + a 32-bit lane offset
+    computed inside the step, the stores asm statements.  Checked: between the first and the last fused statement (an MFMA and a
+    v_fmac_f64 / v_ldexp_f64 in ONE asm statement) of every overlapped step there is no scratch access, every store is an asm
+    store with its wait state, and the stream's three instructions ride in the MFMA's statement."""
+    ks = _kernels(asm["slice_gemm.hip"], "slice_gemm_w_kernel")
+    breg = {n: b for n, b in ks.items() if (_varw(n) & 16384) and (_varw(n) & 32768)}
+    assert breg
+    steps = 0
+    for name, body in breg.items():
+        lines = body.split("\n")
+        stmts, cur = [], None            # (first line, last line, text) of every asm statement
+        for i, l in enumerate(lines):
+            if "#ASMSTART" in l:
+                cur = [i, i, []]
+            elif "#ASMEND" in l and cur is not None:
+                cur[1] = i
+                stmts.append((cur[0], cur[1], "\n".join(cur[2])))
+                cur = None
+            elif cur is not None:
+                cur[2].append(l)
+        fused = [(a, b) for a, b, t in stmts if "v_mfma_i32_16x16x64_i8" in t and ("v_fmac_f64" in t or "v_ldexp_f64" in t)]
+        if not fused:
+            continue                     # (a first pass of a two-pass mode: 9 diagonals, never final - the step is compiled all the same)
+        runs, start, prev = [], fused[0][0], fused[0][1]
+        for a, b in fused[1:]:
+            if a - prev > 400:
+                runs.append((start, prev))
+                start = a
+            prev = b
+        runs.append((start, prev))
+        for a, b in runs:
+            span = lines[a:b + 1]
+            n_fused = sum(1 for x, y in fused if a <= x <= b)
+            if n_fused < 150:
+                continue
+            steps += 1
+            text = "\n".join(span)
+            assert "scratch_" not in text, f"{name}: scratch access inside an overlapped step"
+            assert n_fused >= 3 * 8 * 9 - 8, (name, n_fused)      # three blocks x 72 elements accumulate inside MFMA statements
+            in_asm = False
+            drains = 0
+            for l in span:
+                if "#ASMSTART" in l:
+                    in_asm = True
+                elif "#ASMEND" in l:
+                    in_asm = False
+                elif not in_asm and not l.strip().startswith(";"):
+                    assert "global_store" not in l, f"{name}: compiler-generated store inside an overlapped step: {l.strip()}"
+                    drains += bool(re.search(r"s_waitcnt vmcnt\(0\)", l))
+            # (one wait for the row / column scales loaded at the step's start, in front of their first use a block later; the
+            # beta != 0 arm waits for the old C it loaded a block ahead - never one per store)
+            assert drains <= 6, f"{name}: {drains} full vmcnt drains inside an overlapped step"
+    assert steps >= 2        # the 64 x 128 tile and the half-height tile of fp64_int8_9

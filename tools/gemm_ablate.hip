@@ -175,7 +175,106 @@ int main(int argc, char **argv) {
     bool nophase;
     std::vector<float> ms;
   };
-#ifdef ABLATE_SCHEDULE // -DABLATE_SCHEDULE [-DABLATE_S=n -DABLATE_WA=w]: copy spacing / barrier position of the wide kernel's k-step
+#if defined(ABLATE_TILE_TRACE)
+  // -DABLATE_TILE_TRACE (round 6): where a workgroup of the headline kernel (k64, B in registers, named
+  // accumulators, recombination under the last step, persistent with the ticket drawn one tile ahead) spends its time ACROSS tile
+  // boundaries.  Run:  tools/bin/gemm_ablate_ttrace N rounds mask M K spec_kb [1: drain the stores before the tile's last stamp]
+  //   8192^2 x 256:   tools/bin/gemm_ablate_ttrace 8192 5 127 8192 256
+  //   32768^2 x 1024: tools/bin/gemm_ablate_ttrace 32768 3 127 32768 1024
+  {
+    constexpr int Z = VARW_K64 | VARW_BREG | VARW_ACCN;
+    (void)sizeof(Var);
+    unsigned long long *trace = nullptr;
+    const size_t trace_words = 16384 + (size_t)256 * 40 * 16;
+    CK(hipMalloc(&trace, trace_words * 8));
+    a.acc = reinterpret_cast<double *>(trace);
+    a.epi_overlap = 1;
+    a.dump_only = argc > 7 ? std::atoi(argv[7]) : 0;
+    std::vector<float> plain, traced;
+    for (int r = 0; r < rounds + 1; r++) {
+      const float t0 = run_w<S, 2, Z, 0, -1, 8, 12, false, true>(a, st, e0, e1);
+      CK(hipMemsetAsync(trace, 0, trace_words * 8, st));
+      const float t1 = run_w<S, 2, Z | VARW_TRACE, 0, -1, 8, 12, false, true>(a, st, e0, e1);
+      if (r) {
+        plain.push_back(t0);
+        traced.push_back(t1);
+      }
+    }
+    if (M * N <= (size_t)8192 * 8192) { // bitwise: the overlapped recombination against the plain epilogue of the LDS-staged form
+      constexpr int Y = VARW_K64 | VARW_B1;
+      std::vector<double> c0(M * N), c1(M * N);
+      CK(hipMemset(C, 0xFF, 8 * M * N));
+      run_w<S, 2, Y, 0, -1, 8, 12, false, true>(a, st, e0, e1);
+      CK(hipMemcpy(c0.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
+      CK(hipMemset(C, 0xFF, 8 * M * N));
+      run_w<S, 2, Z, 0, -1, 8, 12, false, true>(a, st, e0, e1);
+      CK(hipMemcpy(c1.data(), C, 8 * M * N, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < M * N; i++) bad += std::memcmp(&c0[i], &c1[i], 8) != 0;
+      std::printf("overlapped recombination (B->VGPR) vs plain epilogue (B via LDS): %zu mismatching elements of %zu\n", bad, M * N);
+    }
+    std::sort(plain.begin(), plain.end());
+    std::sort(traced.begin(), traced.end());
+    const double ops = (double)(S * (S + 1) / 2) * 2.0 * M * N * K;
+    std::printf("# %zu x %zu x %zu, S = %d, k64 B->VGPR named accumulators, overlapped last step, persistent (claim ahead <= %u k-blocks)%s\n", M, N, K, S,
+                a.spec_claim_kb, a.dump_only & 1 ? ", stores DRAINED before the tile's last stamp" : "");
+    std::printf("kernel: %.3f ms (%.1f TOPS) untraced, %.3f ms with the stamps (median of %d)\n", plain[plain.size() / 2],
+                ops / plain[plain.size() / 2] / 1e9, traced[traced.size() / 2], rounds);
+    std::vector<unsigned long long> h(trace_words);
+    CK(hipMemcpy(h.data(), trace, trace_words * 8, hipMemcpyDeviceToHost));
+    // phases of every interior tile (not a workgroup's first or last one), overlapped form, in 10 ns ticks
+    const char *names[8] = {"claim + entry (previous tile's end -> ticket in hand)", "prologue issue (first stage's copies, next ticket)",
+                            "prologue wait (first stage lands, barrier)", "k loop but the last step", "last step (+ blocks 0..2 recombined, stored)",
+                            "last block's chain + stores issued", "whole tile", "shader clock [MHz]"};
+    std::vector<double> ph[8];
+    size_t tiles = 0, plain_tiles = 0;
+    for (int wg = 0; wg < 256; wg++) {
+      const unsigned long long n = std::min<unsigned long long>(h[wg], 40);
+      for (unsigned long long q = 1; q + 1 < n; q++) {
+        const unsigned long long *r = &h[16384 + ((size_t)wg * 40 + q) * 16], *rp = r - 16;
+        if (!(r[9] & 1)) {
+          plain_tiles++;
+          continue;
+        }
+        tiles++;
+        ph[0].push_back((double)(r[0] - rp[5]));
+        for (int i = 1; i <= 5; i++) ph[i].push_back((double)(r[i] - r[i - 1]));
+        ph[6].push_back((double)(r[5] - rp[5]));
+        ph[7].push_back((double)(r[7] - r[6]) / ((double)(r[5] - r[0]) * 0.01));
+      }
+    }
+    std::printf("interior tiles traced: %zu overlapped (+ %zu in the plain form, not tabulated); tiles per workgroup: %llu .. %llu\n", tiles, plain_tiles,
+                *std::min_element(h.begin(), h.begin() + 256), *std::max_element(h.begin(), h.begin() + 256));
+    double clock_mhz = 0;
+    for (int i = 0; i < 8; i++) {
+      if (ph[i].empty()) continue;
+      std::sort(ph[i].begin(), ph[i].end());
+      double mean = 0;
+      for (double v : ph[i]) mean += v;
+      mean /= (double)ph[i].size();
+      const double sc = i == 7 ? 1.0 : 0.01; // ticks -> us
+      if (i == 7) clock_mhz = ph[i][ph[i].size() / 2];
+      std::printf("  %-56s median %8.2f  mean %8.2f  p10 %8.2f  p90 %8.2f %s\n", names[i], ph[i][ph[i].size() / 2] * sc, mean * sc,
+                  ph[i][ph[i].size() / 10] * sc, ph[i][ph[i].size() * 9 / 10] * sc, i == 7 ? "" : "us");
+    }
+    const double steps = (double)(a.KB / 2), mfma_cycles = steps * 360.0 * 16.0;
+    if (clock_mhz > 0)
+      std::printf("  MFMA issue time of a tile at that clock: %.2f us (%g steps x 360 x 16 cycles), of its last step: %.2f us\n", mfma_cycles / clock_mhz,
+                  steps, 360.0 * 16.0 / clock_mhz);
+    // one workgroup's consecutive tiles, raw (us since its first stamp)
+    for (int wg : {0, 100}) {
+      const unsigned long long n = std::min<unsigned long long>(h[wg], 6);
+      const unsigned long long t0 = h[16384 + (size_t)wg * 40 * 16];
+      for (unsigned long long q = 0; q < n; q++) {
+        const unsigned long long *r = &h[16384 + ((size_t)wg * 40 + q) * 16];
+        std::printf("  wg %3d tile %llu (rb0 %llu tn %llu xcd %llu %s):", wg, q, r[8] >> 32, r[8] & 0xffffffffull, r[9] >> 8, r[9] & 1 ? "ovl" : "plain");
+        for (int i = 0; i < 6; i++) std::printf(" %8.2f", (double)(r[i] - t0) * 0.01);
+        std::printf("\n");
+      }
+    }
+    return 0;
+  }
+#elif defined(ABLATE_SCHEDULE) // -DABLATE_SCHEDULE [-DABLATE_S=n -DABLATE_WA=w]: copy spacing / barrier position of the wide kernel's k-step
 #ifndef ABLATE_WA
 #define ABLATE_WA 3
 #endif
