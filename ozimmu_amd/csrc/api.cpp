@@ -939,6 +939,10 @@ int ozimmu_hip_create(ozimmu_hip_handle_t *handle, ozimmu_malloc_mode_t mm) { //
     *handle = nullptr;
     return 3;
   }
+  if (hipHostMalloc((void **)&h->h_mantissa_loss_pinned, sizeof(unsigned long long) * 16, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    h->h_mantissa_loss_pinned = nullptr; // (the statistic then lands in pageable memory, as before)
+  }
   for (auto &e : h->ev) hipEventCreate(&e);
   hipEventCreateWithFlags(&h->tail_ev, hipEventDisableTiming);
   probe_topology(h->device); // once per device: CU / XCD count, sustained MFMA time (the launch policy plans with them)
@@ -1084,6 +1088,7 @@ int ozimmu_hip_destroy(ozimmu_hip_handle_t h) { // src/handle.cu:35-52
     }
     if (h->working_memory_ptr) hipFree(h->working_memory_ptr);
     if (h->d_mantissa_loss_counter_ptr) hipFree(h->d_mantissa_loss_counter_ptr);
+    if (h->h_mantissa_loss_pinned) hipHostFree(h->h_mantissa_loss_pinned);
     if (h->exp_words) hipFree(h->exp_words);
     for (void *p : h->retired_blocks) hipFree(p);
     for (auto &e : h->ev)
@@ -1349,9 +1354,10 @@ static int mantissa_loss_impl(ozimmu_hip_handle_t h, ozimmu_operation_t op_A, oz
     h->exp_reuse.m = m, h->exp_reuse.n = n, h->exp_reuse.k = k;
     h->exp_reuse.op_a = (int)op_A, h->exp_reuse.op_b = (int)op_B, h->exp_reuse.parts = parts;
   }
-  unsigned long long host[16];
+  unsigned long long stack_host[16];
+  unsigned long long *host = h->h_mantissa_loss_pinned ? h->h_mantissa_loss_pinned : stack_host;
   // blocking download, as src/split.cu:404-408
-  if (!hip_ok(hipMemcpyAsync(host, h->d_mantissa_loss_counter_ptr, sizeof(host), hipMemcpyDeviceToHost, h->stream),
+  if (!hip_ok(hipMemcpyAsync(host, h->d_mantissa_loss_counter_ptr, sizeof(stack_host), hipMemcpyDeviceToHost, h->stream),
               "memcpy") ||
       !hip_ok(hipStreamSynchronize(h->stream), "sync"))
     return 3;

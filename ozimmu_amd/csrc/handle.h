@@ -29,6 +29,7 @@ struct ozimmu_hip_handle {
 
   // auto mode: 16 counters for S = 3..18 (the reference allocates 8: src/handle.hpp:22)
   unsigned long long *d_mantissa_loss_counter_ptr = nullptr;
+  unsigned long long *h_mantissa_loss_pinned = nullptr; // the counters' landing place on the host (pinned: the blocking copy of src/split.cu:404-408 without a staging hop)
 
   // row exponent words of the split (kernels.h: SplitJobs::tag): a buffer that holds nothing else, written with a tag
   // that grows from call to call, so that it is zeroed once when it is allocated and never per call

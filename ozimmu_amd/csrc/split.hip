@@ -682,47 +682,79 @@ hipError_t launch_untile(const int8_t *planes, size_t rows, size_t K, int S, int
 }
 
 // ---- auto mode: mantissa-loss statistic (src/split.cu:317-380) ---------------------------------------
+// Per non-zero element of a live row: req = (e_max + 1 - e_in) + 53; loss_S = max(0, req - S L) for S = 3 .. 18; the 16 sums
+// over the operand.  Round 6: the first form gave every wave ONE 32 x 32 block - ~50 VALU instructions per element and mode
+// sweep, then 96 shuffles, 16 LDS atomics and (per workgroup) 16 global atomics per 8 KiB read - and took 231 / 253 us per 8192^2
+// operand where its own row-maximum pass reads the same bytes in 89 / 99 us (profiles/r6_ablate/r6i_trace_auto_8192.txt): the
+// statistic cost fp64_int8_auto 5 % of an 8192^3 call.  Now: persistent waves walk the blocks with a grid stride and reduce ONCE;
+// the 16 modes are 8 pairs of packed 16-bit lanes (req <= 2100, a block's 16 elements per lane sum to <= 33 600 < 2^16):
+// v_pk_sub_i16, v_pk_max_i16, v_pk_add_u16 per pair and element, widened to 32 bits per block; k-contiguous operands are not
+// transposed through LDS any more (an element needs its row's exponent, not its row's neighbours).  Same integer sums.
+typedef short pk_i16 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
+
 template <bool KCONTIG>
 __global__ __launch_bounds__(256) void mantissa_loss_kernel(const double *__restrict__ in, size_t rows,
                                                             size_t K, size_t sr, size_t sk,
                                                             const uint32_t *__restrict__ exps, int L,
                                                             unsigned long long *counters, size_t RB,
                                                             size_t KB, uint32_t tag) {
-  __shared__ double tiles[KCONTIG ? 4 : 1][32][33];
   __shared__ unsigned long long blk[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 16) blk[threadIdx.x] = 0;
   __syncthreads();
-  const size_t gw = (size_t)blockIdx.x * 4 + wave;
-  unsigned loss[16];
+  pk_i16 thr[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) thr[i] = pk_i16{(short)((3 + 2 * i) * L), (short)((4 + 2 * i) * L)};
+  unsigned long long loss[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) loss[i] = 0;
-  if (gw < RB * KB) {
+  const size_t nblk = RB * KB, stride = (size_t)gridDim.x * 4;
+  for (size_t gw = (size_t)blockIdx.x * 4 + wave; gw < nblk; gw += stride) {
     const size_t rb = KCONTIG ? gw / KB : gw % RB;
     const size_t kb = KCONTIG ? gw % KB : gw / RB;
-    double v[16];
-    load_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, tiles[KCONTIG ? wave : 0], v);
-    const size_t rg = rb * 32 + (lane & 31);
-    const unsigned e = rg < rows ? tagged_exp(exps[rg], tag) : 0u;
-    if (e != 0u && e != 0x7FFu) { // max_exp != 0 (src/split.cu:322); non-finite rows carry no statistic
+    double t[16];
+    fetch_block<KCONTIG>(in, rows, K, sr, sk, rb, kb, lane, t);
+    // the row of element q: row-contiguous operands: the lane's one row; k-contiguous: row 2 q + (lane >> 5) of the block
+    unsigned e[KCONTIG ? 16 : 1];
+    if constexpr (KCONTIG) {
 #pragma unroll
       for (int q = 0; q < 16; q++) {
-        if (v[q] == 0.0) continue; // src/split.cu:322
-        const unsigned req = (e + 1u - exp_field(v[q])) + 53u; // :325-329
-#pragma unroll
-        for (int s = 3; s <= 18; s++) { // :330-337
-          const unsigned space = (unsigned)(s * L);
-          loss[s - 3] += space < req ? req - space : 0u;
-        }
+        const size_t rg = rb * 32 + q * 2 + (lane >> 5);
+        e[q] = rg < rows ? tagged_exp(exps[rg], tag) : 0u;
       }
+    } else {
+      const size_t rg = rb * 32 + (lane & 31);
+      e[0] = rg < rows ? tagged_exp(exps[rg], tag) : 0u;
+    }
+    pk_u16 part[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) part[i] = pk_u16{0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const unsigned eq = e[KCONTIG ? q : 0];
+      // max_exp != 0 (src/split.cu:322); non-finite rows carry no statistic; zero elements are skipped (:322)
+      const bool live = eq != 0u && eq != 0x7FFu && t[q] != 0.0;
+      const short req = live ? (short)((eq + 1u - exp_field(t[q])) + 53u) : (short)0; // :325-329 (<= 2100)
+      const pk_i16 r2 = pk_i16{req, req};
+#pragma unroll
+      for (int i = 0; i < 8; i++) { // :330-337, two modes per instruction
+        const pk_i16 d = __builtin_elementwise_max(r2 - thr[i], pk_i16{0, 0});
+        part[i] += __builtin_bit_cast(pk_u16, d);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      loss[2 * i] += part[i].x;
+      loss[2 * i + 1] += part[i].y;
     }
   }
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    unsigned x = loss[i];
+    unsigned long long x = loss[i];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-    if (lane == 0 && x) atomicAdd(&blk[i], (unsigned long long)x);
+    if (lane == 0 && x) atomicAdd(&blk[i], x);
   }
   __syncthreads();
   if (threadIdx.x < 16 && blk[threadIdx.x]) atomicAdd(counters + threadIdx.x, blk[threadIdx.x]);
@@ -732,7 +764,8 @@ hipError_t launch_mantissa_loss(const OperandView &v, const uint32_t *exps, int 
                                 unsigned long long *counters, hipStream_t stream, uint32_t tag) {
   const size_t RB = (v.rows + 31) / 32, KB = k_blocks(v.K);
   if (RB * KB == 0) return hipSuccess;
-  const unsigned grid = (unsigned)((RB * KB + 3) / 4);
+  // persistent waves: eight workgroups of four waves per CU of a 256-CU part keep the memory system busy; fewer for small operands
+  const unsigned grid = (unsigned)std::min<size_t>((RB * KB + 3) / 4, 2048);
   if (v.stride_k < v.stride_r)
     hipLaunchKernelGGL(mantissa_loss_kernel<true>, dim3(grid), dim3(256), 0, stream, v.in, v.rows, v.K,
                        v.stride_r, v.stride_k, exps, L, counters, RB, KB, tag);
