@@ -59,7 +59,8 @@ static double g_params[POLICY_PARAMS] = {
     /* W   a, beta, b, step           */ 0.835, 0.1284, 0, 0.3188,
     /* X   a, beta, b, step           */ 0.7832, 0, 1.144, 0.4425,
     /* Y   a, beta, b, step           */ 0.6964, 0.02605, 1.986, 0.4175,
-    /* Z   a, beta, b, step           */ 0.7466, 0, 5.304, 0,
+    /* Z   a, beta, b, step           */ 0.7466, 0, 3.5, 0, // (b: 5.304 until round 6 took ~1.8 us off the register kernel's tile boundary -
+                                                           // profiles/r6_ablate/; 250 forced-kernel rows of this round, gpurun r6j: least mean regret at 3.5)
     /* wide f, gamma, epi_w, epi_y    */ 1.1, 0.7485, 0.1655, 0.1439,
     /* C us per MB                    */ 0.1323,
     /* cl drift, store per block      */ 0, 0.9538,
