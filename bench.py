@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--no-extra", action="store_true", help="skip residual / rocBLAS comparison")
     p.add_argument("--no-traffic", action="store_true",
                    help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic")
+    p.add_argument("--no-ceiling", action="store_true",
+                   help="do not run the 2 s MFMA-only probe behind roofline.frac_of_measured_mfma_ceiling (profiling runs: it would be 90 % of the trace)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise the RCCL process group even with one rank (exercises the N > 1 timing path on one GPU)")
     p.add_argument("--no-configs", action="store_true",
@@ -68,7 +70,7 @@ def measure_traffic(args, kernel_substr="slice_gemm"):
     if not os.path.exists(rocprof):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extra",
-             "--no-traffic", "--quiet", "--n", str(args.n), "--m", str(args.m), "--k", str(args.k), "--mode", args.mode,
+             "--no-traffic", "--no-ceiling", "--quiet", "--n", str(args.n), "--m", str(args.m), "--k", str(args.k), "--mode", args.mode,
              "--opa", args.opa, "--opb", args.opb]
     res = {}
     names = {}
@@ -505,6 +507,8 @@ def main():
         # power limited under full-entropy INT8 MFMA (profiles/r3_power_bound.md: ~3 950 of the nominal 5 033 TOPS), so `frac`
         # (vs the nominal peak, kept as it is) cannot reach 1 for any kernel; this one can
         try:
+            if args.no_ceiling:
+                raise RuntimeError("skipped (--no-ceiling)")
             ceiling = oz.mfma_ceiling(2.0)
             out["roofline"]["measured_mfma_ceiling"] = round(ceiling, 1)
             out["roofline"]["frac_of_measured_mfma_ceiling"] = round(achieved / ceiling, 4)

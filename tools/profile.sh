@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extra --no-traffic $*"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-extra --no-traffic --no-ceiling $*"
 
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 tail -2 $OUT/trace.log
