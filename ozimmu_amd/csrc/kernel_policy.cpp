@@ -53,18 +53,20 @@ static_assert(DEV_MFMA_US + 1 == POLICY_PARAMS, "parameter table");
 // and this term is what separates the kernels.
 
 static double g_params[POLICY_PARAMS] = {
-    /* K2  a, beta, f, step           */ 1.115, 0, 0, 0,
-    /* CL  a, a1, beta, b, f, step    */ 1.023, 1.27, 0, 0, 0, 0.107,
-    /* CL4 a, step                    */ 0.9487, 0.6612,
-    /* W   a, beta, b, step           */ 0.835, 0.1284, 0, 0.3188,
-    /* X   a, beta, b, step           */ 0.7832, 0, 1.144, 0.4425,
-    /* Y   a, beta, b, step           */ 0.6964, 0.02605, 1.986, 0.4175,
-    /* Z   a, beta, b, step           */ 0.7466, 0, 3.5, 0, // (b: 5.304 until round 6 took ~1.8 us off the register kernel's tile boundary -
-                                                           // profiles/r6_ablate/; 250 forced-kernel rows of this round, gpurun r6j: least mean regret at 3.5)
-    /* wide f, gamma, epi_w, epi_y    */ 1.1, 0.7485, 0.1655, 0.1439,
-    /* C us per MB                    */ 0.1323,
-    /* cl drift, store per block      */ 0, 0.9538,
-    /* cl epi, cl C us per MB, round  */ 0.09293, 0, 3.513,
+    // Round 6 refit (profiles/r6_policy/fit_r6_log.txt): the register kernel's tile boundary changed (profiles/r6_ablate/), so its rows
+    // are this round's - 250 shapes at S = 9, 90 of them short-K panels, every kernel forced - next to the round-5 rows of the
+    // other modes.  Regret on those 1 289 cases 0.71 -> 0.63 % mean, cases above 3 % 114 -> 99; on the S = 9 rows alone 1.61 -> 1.20 %.
+    /* K2  a, beta, f, step           */ 1.021, 0, 0, 0.001605,
+    /* CL  a, a1, beta, b, f, step    */ 1.049, 1.241, 0, 0, 0, 0.1006,
+    /* CL4 a, step                    */ 0.994, 0.6352,
+    /* W   a, beta, b, step           */ 0.7995, 0.3492, 0.4029, 0.3186,
+    /* X   a, beta, b, step           */ 0.7948, 0, 1.3, 0.4383,
+    /* Y   a, beta, b, step           */ 0.6875, 0.1166, 2.324, 0.4263,
+    /* Z   a, beta, b, step           */ 0.5214, 1.328, 3.155, 0,
+    /* wide f, gamma, epi_w, epi_y    */ 1.138, 0.7529, 0.1499, 0.1394,
+    /* C us per MB                    */ 0.1487,
+    /* cl drift, store per block      */ 0, 0.7503,
+    /* cl epi, cl C us per MB, round  */ 0.06178, 0, 3.687,
     0.0, 0.0};
 
 static std::mutex g_params_mtx;
