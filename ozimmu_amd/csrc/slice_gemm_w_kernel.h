@@ -748,6 +748,25 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// the prologue hook of the persistent kernels' tiles (slice_gemm_y_tile.h: prologue_hook): phase 1 draws the NEXT tile's ticket
+template <bool SPEC>
+struct TicketHook {
+  uint32_t *ticket;      // thread 0's spec_t
+  uint32_t **counter;    // ... spec_cnt
+  const uint32_t *region; // ... spec_region (0: nothing to draw)
+  template <class P>
+  __device__ __forceinline__ void operator()(P) const {
+    if constexpr (SPEC && P::value == 1) {
+      if (threadIdx.x == 0 && *region) {
+        const uint32_t one = 1u;
+        uint32_t t;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(*counter), "v"(one) : "memory");
+        *ticket = t;
+      }
+    }
+  }
+};
+
 template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0, int DMAE, int TAIL_, bool MULTI>
 __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int count, char *smem) {
   const SliceGemmArgs &p = g[0];
@@ -795,17 +814,12 @@ __device__ __forceinline__ void w_persistent(const SliceGemmArgs *g, const int c
   // (Round 4 issued the atomic at the tile boundary and waited for it one tile later: between the two the destination VGPR was
   // in flight while the compiler believed it defined - a copy or a spill inside that window would have captured a stale
   // ticket; ADVICE r4.  tests/test_isa_invariants.py: every returning atomic of these kernels is followed by its wait.)
-  auto draw_ticket = [&]() {
-    if constexpr (SPECULATE) {
-      if (threadIdx.x == 0 && spec_region) {
-        const uint32_t one = 1u;
-        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(spec_t)
-                     : "v"(spec_cnt), "v"(one)
-                     : "memory");
-      }
-    }
-  };
+  // (Round 6 also tried issuing the atomic in FRONT of the tile's copies - into v255, an accumulator register that is dead until the
+  // first k-step - and collecting it behind them: the round trip then overlaps the ~1 us the 27 copies take to issue.  Measured
+  // (profiles/r6_ablate/r6p_*): the ticket's wait went 0.72 -> 0.36 us, but wave 0's copies queue behind the atomic - "copies issued"
+  // 1.0 -> 1.1 us at 32768^2 x 1024 and -> 1.7 us at 8192^2 x 256, where every workgroup of an XCD draws from one counter at the same
+  // moment: neutral to negative.  Dropped.)
+  const TicketHook<SPECULATE> draw_ticket{&spec_t, &spec_cnt, &spec_region};
   for (;;) {
     uint32_t kind = 0, lid = 0; // 1: big tile `lid` of its region, 2: small tile, 0: nothing left
     if (!p.queue) {

@@ -85,10 +85,13 @@ inline constexpr YSched<S, WA> kYSched{};
 #ifndef OZ_Y_RING
 #define OZ_Y_RING 4 // A fragment ring entries (tools/gemm_ablate.hip -DOZ_Y_RING=n: A/B)
 #endif
-// `prologue_hook()` runs between the issue of the first stage's copies and the wait for them: whatever round trip it makes
-// (w_persistent: the NEXT tile's claim ticket) hides under the latency this tile waits out anyway.
+// `prologue_hook(phase)`: phase 1 runs between the issue of the first stage's copies and the wait for them: whatever round trip it
+// makes (w_persistent: the NEXT tile's claim ticket) hides under the latency this tile waits out anyway; phase 0 runs in FRONT of
+// the copies (round 6 tried the ticket's atomic there, collected in phase 1: neutral to negative, slice_gemm_w_kernel.h; the phase stays
+// for the next idea).
 struct NoHook {
-  __device__ __forceinline__ void operator()() const {}
+  template <class P>
+  __device__ __forceinline__ void operator()(P) const {}
 };
 template <int S, int D0, int ND, int WA, int VARW, int STAG, int DMA0_, int DMAE_, int TAIL_, int RING = OZ_Y_RING, class HOOK = NoHook>
 __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const uint32_t rb0, const uint32_t tn,
@@ -134,7 +137,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
   // 3: in front of the last step, 4: behind it, 5: epilogue issued (p.dump_only & 1: and its stores drained), + the shader
   // cycles (s_memtime) at 0 and 5.  A stamp waits for the scalar memory path (lgkmcnt(0)): a few tens of cycles each.
   constexpr bool TTRACE = (VARW & VARW_TRACE) != 0;
-  unsigned long long tt[TTRACE ? 6 : 1] = {}, tcyc[TTRACE ? 2 : 1] = {};
+  unsigned long long tt[TTRACE ? 8 : 1] = {}, tcyc[TTRACE ? 2 : 1] = {}; // (6, 7: inside the prologue - set-up done, copies issued)
   auto tstamp = [&](auto ic) {
     if constexpr (TTRACE) {
       unsigned long long t;
@@ -165,6 +168,8 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
           r[7] = tcyc[1];
           r[8] = ((unsigned long long)rb0 << 32) | tn;
           r[9] = (overlapped ? 1ull : 0ull) | ((unsigned long long)xcd << 8);
+          r[10] = tt[6];
+          r[11] = tt[7];
         }
       }
     }
@@ -358,6 +363,8 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
 
   // ---- prologue -----------------------------------------------------------------------------------------------
   uint32_t k_issue = koff;
+  tstamp(std::integral_constant<int, 6>{});
+  prologue_hook(std::integral_constant<int, 0>{});
   if (0u < nk) {
     static_for<NDMA>([&](auto cc) { copy_n(cc, 0, 0, k_issue, std::integral_constant<int, 0>{}); });
     static_for<2 * NHI>([&](auto cc) {
@@ -365,7 +372,8 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     });
     k_issue = koff_next(k_issue);
   }
-  prologue_hook();
+  tstamp(std::integral_constant<int, 7>{});
+  prologue_hook(std::integral_constant<int, 1>{});
   tstamp(std::integral_constant<int, 1>{});
   if constexpr (!NO_GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (!MFMA_ONLY) {
@@ -451,7 +459,7 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     e_rmw = p.beta != 0.0;
     e_boff = ((nl + (ln & 1u)) * (uint32_t)p.ldc + (ln & 14u)) * 8u; // (< 2^32: the overlapped form runs for ldc < 2^25)
 #pragma unroll
-    for (int a = 0; a < MA; a++) e_ea[a] = p.ea[e_mu + (ln & 15u) + 16 * a];
+    for (int a = 0; a < MA; a++) e_ea[a] = 0x1p-44 * p.ea[e_mu + (ln & 15u) + 16 * a];
     const double *eb_lane = p.eb + e_nu + nl;
 #pragma unroll
     for (int b = 0; b < 2; b++)
@@ -497,11 +505,20 @@ __device__ __forceinline__ void y_tile(const SliceGemmArgs &p, char *smem, const
     constexpr int A = decltype(a_tag)::value, u = decltype(u_tag)::value, q = decltype(q_tag)::value;
     constexpr int b = u >> 1, vp = u & 1;
     if constexpr (q == 0) {
-      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141)
-      e_v0 = e_xx[2 * u] * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp];
-      e_v1 = e_xx[2 * u + 1] * 0x1p-44 * e_ea[A] * e_eb[4 * b + 2 * vp + 1];
+      // reference: x_ptr[tid] / (1l << 44) * a_max_exp[mi] * b_max_exp[ni]  (src/gemm.cu:140-141).  e_ea holds 2^-44 * a_max_exp
+      // (epi_setup): x * 2^-44 is exact (|x| >= 2^-24 or 0) and so is 2^-44 * 2^(e+1) (>= 2^-1065, a representable power of
+      // two), so (x * 2^-44) * ea and x * (2^-44 * ea) are the SAME real number rounded once - one multiplication less per output
+      e_v0 = e_xx[2 * u] * e_ea[A] * e_eb[4 * b + 2 * vp];
+      e_v1 = e_xx[2 * u + 1] * e_ea[A] * e_eb[4 * b + 2 * vp + 1];
     } else {
-      const double s0 = lane_pair_swap(e_v0), s1 = lane_pair_swap(e_v1);
+      // (the neighbour's value by ONE v_mov_b32_dpp per word: lane_pair_swap's update_dpp form hands the builtin an `old` operand
+      // and costs a register copy in front of every DPP move - all lanes are written here, there is no old value to keep)
+      auto swap = [](double v) {
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+      };
+      const double s0 = swap(e_v0), s1 = swap(e_v1);
       double2 y;
       y.x = e_odd ? s1 : e_v0; // row 2i:     (column n from this lane | column n+1 from the even neighbour)
       y.y = e_odd ? e_v1 : s0; // row 2i + 1: (column n from the odd neighbour | column n+1 from this lane)

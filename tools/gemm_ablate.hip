@@ -226,7 +226,7 @@ int main(int argc, char **argv) {
     const char *names[8] = {"claim + entry (previous tile's end -> ticket in hand)", "prologue issue (first stage's copies, next ticket)",
                             "prologue wait (first stage lands, barrier)", "k loop but the last step", "last step (+ blocks 0..2 recombined, stored)",
                             "last block's chain + stores issued", "whole tile", "shader clock [MHz]"};
-    std::vector<double> ph[8];
+    std::vector<double> ph[8], pro[3];
     size_t tiles = 0, plain_tiles = 0;
     for (int wg = 0; wg < 256; wg++) {
       const unsigned long long n = std::min<unsigned long long>(h[wg], 40);
@@ -240,6 +240,9 @@ int main(int argc, char **argv) {
         ph[0].push_back((double)(r[0] - rp[5]));
         for (int i = 1; i <= 5; i++) ph[i].push_back((double)(r[i] - r[i - 1]));
         ph[6].push_back((double)(r[5] - rp[5]));
+        pro[0].push_back((double)(r[10] - r[0]));  // set-up: pointers, lane offsets, phase
+        pro[1].push_back((double)(r[11] - r[10])); // the first stage's copies issued
+        pro[2].push_back((double)(r[1] - r[11]));  // the next ticket (hook)
         ph[7].push_back((double)(r[7] - r[6]) / ((double)(r[5] - r[0]) * 0.01));
       }
     }
@@ -256,6 +259,13 @@ int main(int argc, char **argv) {
       if (i == 7) clock_mhz = ph[i][ph[i].size() / 2];
       std::printf("  %-56s median %8.2f  mean %8.2f  p10 %8.2f  p90 %8.2f %s\n", names[i], ph[i][ph[i].size() / 2] * sc, mean * sc,
                   ph[i][ph[i].size() / 10] * sc, ph[i][ph[i].size() * 9 / 10] * sc, i == 7 ? "" : "us");
+    }
+    const char *pn[3] = {"  prologue: set-up (pointers, offsets)", "  prologue: first stage's copies issued", "  prologue: next ticket drawn (atomic round trip)"};
+    for (int i = 0; i < 3; i++) {
+      if (pro[i].empty()) continue;
+      std::sort(pro[i].begin(), pro[i].end());
+      std::printf("  %-56s median %8.2f  p10 %8.2f  p90 %8.2f us\n", pn[i], pro[i][pro[i].size() / 2] * 0.01, pro[i][pro[i].size() / 10] * 0.01,
+                  pro[i][pro[i].size() * 9 / 10] * 0.01);
     }
     const double steps = (double)(a.KB / 2), mfma_cycles = steps * 360.0 * 16.0;
     if (clock_mhz > 0)
