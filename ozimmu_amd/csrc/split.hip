@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include <type_traits>
@@ -565,7 +566,12 @@ hipError_t launch_split_fused(const SplitJob *job, int count, int S, int L, hipS
 }
 
 
-template <int R, bool LOW>
+// UNITS: unit blocks a wave holds at most (1, 2 or RES_UNITS = 4).  The strip of a short K (K <= 256 / 512 at 32 rows) is one or two
+// blocks per wave, and the kernel compiled for four keeps 167 registers: ONE workgroup of 8 waves per CU, whose load, row maximum, cut
+// (VALU bound: ~860 instructions per block) and stores run one after the other with nothing else on the CU.  Compiled for the blocks it
+// really holds it needs half the registers, two or three workgroups share a CU and one's loads run under another's cut
+// (8192 x 256 x 2 operands: profiles/r6_ablate/README.md 7).
+template <int R, bool LOW, int UNITS>
 __global__ __launch_bounds__(64 * RES_MAX_WAVES) void split_resident_kernel(const SplitJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) double res_tiles[]; // [waves][RES_TILE_DOUBLES]: k-contiguous views only
   __shared__ unsigned row_e[32];
@@ -588,9 +594,22 @@ __global__ __launch_bounds__(64 * RES_MAX_WAVES) void split_resident_kernel(cons
   j.max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + (size_t)blockIdx.z * jobs.ws_stride);
   double *tile = res_tiles + (size_t)(threadIdx.x >> 6) * RES_TILE_DOUBLES;
   if (j.v.stride_k < j.v.stride_r)
-    split_resident_strip<R, true, LOW>(j, jobs.S, jobs.L, strip, tile, row_e);
+    split_resident_strip<R, true, LOW, UNITS>(j, jobs.S, jobs.L, strip, tile, row_e);
   else
-    split_resident_strip<R, false, LOW>(j, jobs.S, jobs.L, strip, tile, row_e);
+    split_resident_strip<R, false, LOW, UNITS>(j, jobs.S, jobs.L, strip, tile, row_e);
+}
+
+// OZIMMU_HIP_SPLIT_RESIDENT_UNITS=1 / 2 / 4: the smallest instantiation taken (4 = always the general one, the round-5 form: A/B, tests);
+// read once per process like the switches of csrc/config.h, per call under OZIMMU_HIP_ENV_PER_CALL
+static int resident_units_switch() {
+  static std::atomic<int> once{-2};
+  int v = once.load(std::memory_order_relaxed);
+  if (config().env_per_call || v == -2) {
+    const char *e = std::getenv("OZIMMU_HIP_SPLIT_RESIDENT_UNITS");
+    v = e ? std::atoi(e) : -1;
+    once.store(v, std::memory_order_relaxed);
+  }
+  return v;
 }
 
 // the longest K a resident strip (8 rows) can hold: 8 waves x 4 unit blocks x 128 k
@@ -644,10 +663,15 @@ hipError_t launch_split_resident(const SplitJob *job, int count, int S, int L, h
   const size_t lds = any_kcontig ? sizeof(double) * waves * RES_TILE_DOUBLES : 0;
   const dim3 grid((unsigned)total, 1, batch), block(64 * waves);
   const bool low = S * L > 64; // some slice reaches into the lower 64 bits of the shifted mantissa
+  // (the LOW form - S * L > 64: fp64_int8_10 and up - keeps the one instantiation: its 233..242 registers are the 128-bit values)
+  const int forced_units = resident_units_switch();
+  const size_t units = forced_units == 1 || forced_units == 2 || forced_units == 4 ? std::max<size_t>(per_wave, (size_t)forced_units) : per_wave;
 #define OZ_RES_LAUNCH(RR)                                                                                        \
   do {                                                                                                           \
-    if (low) hipLaunchKernelGGL((split_resident_kernel<RR, true>), grid, block, lds, stream, jobs);               \
-    else hipLaunchKernelGGL((split_resident_kernel<RR, false>), grid, block, lds, stream, jobs);                  \
+    if (low) hipLaunchKernelGGL((split_resident_kernel<RR, true, RES_UNITS>), grid, block, lds, stream, jobs);    \
+    else if (units <= 1) hipLaunchKernelGGL((split_resident_kernel<RR, false, 1>), grid, block, lds, stream, jobs); \
+    else if (units <= 2) hipLaunchKernelGGL((split_resident_kernel<RR, false, 2>), grid, block, lds, stream, jobs); \
+    else hipLaunchKernelGGL((split_resident_kernel<RR, false, RES_UNITS>), grid, block, lds, stream, jobs);       \
   } while (0)
   if (R == 32) OZ_RES_LAUNCH(32);
   else if (R == 16) OZ_RES_LAUNCH(16);

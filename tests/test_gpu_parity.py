@@ -18,17 +18,21 @@ from tests.util import ColMajor, exp_rand, operand, uniform01, uniform_pm1, wide
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["resident_split", "resident_split_two_launches", "resident_split_16", "resident_split_32", "multi_view_split", "banded_split", "one_pass_split"])
+@pytest.fixture(autouse=True, params=["resident_split", "resident_split_two_launches", "resident_split_16", "resident_split_32", "resident_split_general", "multi_view_split", "banded_split", "one_pass_split"])
 def split_kernel(request, monkeypatch):
     """every test runs with every split implementation: the resident one-read kernel (what the library does for K <= 2048;
     strips of 8 rows by policy at these sizes - inside the slice GEMM's own launch where the K-split tile runs, csrc/
-    slice_gemm_one_launch.hip, and as a launch of its own with OZIMMU_HIP_ONE_LAUNCH=0 - and forced to 16 and 32), one launch per pass for all operand views (what it does
+    slice_gemm_one_launch.hip, and as a launch of its own with OZIMMU_HIP_ONE_LAUNCH=0 - and forced to 16 and 32; compiled for the
+    one or two unit blocks a wave of a short strip holds, round 6, and - resident_split_general - always for four), one launch per pass for all operand views (what it does
     for longer K), one launch per view walking row bands (operands larger than the Infinity Cache; the band size is forced
     down so that these shapes have several bands), and the one-pass kernel that re-reads its strip from L2"""
     if request.param == "resident_split_two_launches":
         monkeypatch.setenv("OZIMMU_HIP_ONE_LAUNCH", "0")
     elif request.param in ("resident_split_16", "resident_split_32"):
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_RESIDENT", request.param[-2:])
+    elif request.param == "resident_split_general":
+        monkeypatch.setenv("OZIMMU_HIP_ONE_LAUNCH", "0")
+        monkeypatch.setenv("OZIMMU_HIP_SPLIT_RESIDENT_UNITS", "4")
     elif request.param != "resident_split":
         monkeypatch.setenv("OZIMMU_HIP_SPLIT_RESIDENT", "0")
     if request.param == "banded_split":
