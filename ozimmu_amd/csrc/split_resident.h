@@ -33,7 +33,8 @@ __device__ __forceinline__ double max_exp_of(unsigned e) {
 // modes up to fp64_int8_9 at L = 7): the lower words are neither built nor kept (32 registers and a third of the selects)
 // WT = true: the stores are write-through at system scope (sc0 sc1: the data is in memory, not in this XCD's L2, when the
 // store is acknowledged) - for consumers on other XCDs INSIDE the same kernel (slice_gemm_one_launch.hip)
-template <bool LOW = true, bool WT = false>
+// FPBUILD (with LOW = false): the two words by FP64 scaling instead of integer shifts; false = the round-5 form (A/B, parity arm)
+template <bool LOW = true, bool WT = false, bool FPBUILD = true>
 __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e, int S, int L, int8_t *out) {
   const bool live = e != 0u && e < 0x7FEu;
   // 128-bit shifted mantissa W = (m53 << 75) >> off per element (src/split.cu:163-175), built as four 32-bit words
@@ -47,6 +48,19 @@ __device__ __forceinline__ void cut_and_store(const double (&v)[16], unsigned e,
   for (int q = 0; q < 16; q++) {
     const unsigned long long bq = (unsigned long long)__double_as_longlong(v[q]);
     const unsigned bh = (unsigned)(bq >> 32), bl = (unsigned)bq;
+    if constexpr (!LOW && FPBUILD) {
+      // The upper 64 bits of the shifted mantissa by FP64 arithmetic (round 6): they are floor(m53 * 2^(11 - off)) =
+      // floor(|x| * 2^(1085 - e)) - |x| < 2^(e - 1022), so y = |x| * 2^(1053 - e) < 2^31 is an exact scaling (v_ldexp_f64; a result
+      // below the normal range only loses bits far below 2^-64 of the value), its integer part the upper word, and the next 32 bits
+      // the integer part of (y - upper) * 2^32 (the difference is exact).  Subnormal elements scale by their true value, which is the
+      // exponent-field-1 rule above.  6 instructions instead of ~20 selects and funnel shifts per element: the cut is VALU bound.
+      const double y = live ? __builtin_ldexp(__builtin_fabs(v[q]), 1053 - (int)e) : 0.0;
+      const unsigned hi = (unsigned)y;
+      W[q][1] = hi;
+      W[q][0] = (unsigned)__builtin_ldexp(y - (double)hi, 32);
+      if (bh >> 31) negmask[q >> 2] |= 0xFFu << (8 * (q & 3));
+      continue;
+    }
     const unsigned f = (bh >> 20) & 0x7FFu;
     const unsigned mh = (bh & 0xFFFFFu) | (f ? 0x100000u : 0u); // m53 = (mh:bl), 21 + 32 bits
     const unsigned ef = f ? f : 1u; // subnormal: exponent of field 1 (fix of SURVEY §8a quirk 7)
