@@ -593,10 +593,21 @@ __global__ __launch_bounds__(64 * RES_MAX_WAVES) void split_resident_kernel(cons
   j.planes += (size_t)blockIdx.z * jobs.ws_stride;
   j.max_exp = reinterpret_cast<double *>(reinterpret_cast<char *>(j.max_exp) + (size_t)blockIdx.z * jobs.ws_stride);
   double *tile = res_tiles + (size_t)(threadIdx.x >> 6) * RES_TILE_DOUBLES;
-  if (j.v.stride_k < j.v.stride_r)
+  if (j.v.stride_k < j.v.stride_r) {
     split_resident_strip<R, true, LOW, UNITS>(j, jobs.S, jobs.L, strip, tile, row_e);
-  else
+  } else {
+    if constexpr (R == 8 && UNITS >= 2) {
+      // Strips of 8 rows of a ROW-contiguous operand share every 128-byte line (16 rows of one k) with a neighbour, and workgroups go
+      // to the XCDs round robin: neighbours on different XCDs fetch the operand twice, once into each L2.  Inside every aligned group
+      // of 16 of an operand's workgroups the pair (2x, 2x + 1) therefore goes to the two workgroups 8 apart - the same XCD on an
+      // 8-XCD part, a harmless permutation anywhere else.  Measured (profiles/r6_ablate/r6y_*): 1024^2 x 2048 +2...3 % (N/N), +5.8 % (N/T);
+      // at K <= 1024 (one unit block per wave: a latency chain, not bandwidth) the two workgroups queue on the same L2 channel
+      // instead and N/N loses 1 %: not applied there; k-contiguous operands share nothing and are left alone.
+      const uint32_t nb = ji == 0 ? jobs.nblk[0] : ji == 1 ? jobs.nblk[1] : ji == 2 ? jobs.nblk[2] : jobs.nblk[3];
+      if ((strip | 15u) < nb) strip = (strip & ~15u) + ((strip & 7u) << 1) + ((strip >> 3) & 1u);
+    }
     split_resident_strip<R, false, LOW, UNITS>(j, jobs.S, jobs.L, strip, tile, row_e);
+  }
 }
 
 // OZIMMU_HIP_SPLIT_RESIDENT_UNITS=1 / 2 / 4: the smallest instantiation taken (4 = always the general one, the round-5 form: A/B, tests);
