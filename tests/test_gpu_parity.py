@@ -58,7 +58,9 @@ def _sync():
 @pytest.mark.parametrize("matrix", ["A", "B"])
 @pytest.mark.parametrize("op", OPS)
 # (40, 1050): 33 k-blocks, stored as 34 (layout.h: k_blocks keeps the count even beyond 32) - the re-layout must not see it
-@pytest.mark.parametrize("rows,k", [(1, 1), (5, 3), (33, 37), (64, 32), (70, 100), (130, 257), (40, 1050)])
+# (300, 1536), (272, 2048): 40 / 36 strips of 8 rows, two unit blocks per wave - the resident split pairs neighbouring strips of a
+# row-contiguous operand on one XCD there (split.hip, round 6), and its last group of strips is a partial one
+@pytest.mark.parametrize("rows,k", [(1, 1), (5, 3), (33, 37), (64, 32), (70, 100), (130, 257), (40, 1050), (300, 1536), (272, 2048)])
 @pytest.mark.parametrize("S", [3, 9, 18])
 def test_split_bit_exact(oz, matrix, op, rows, k, S):
     import torch
